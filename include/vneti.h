@@ -1,0 +1,155 @@
+/*
+ * vneti.h — C ABI of libvneti_hip.so: the MI355X (gfx950) kernels behind the ViewNeTI
+ * textual-inversion train step.
+ *
+ * The reference (jmhb0/view_neti) has no native/FFI boundary of its own: its hot path runs
+ * through Python protocols into third-party diffusers/transformers modules
+ * (training/coach.py:165-198,211-218; models/xti_attention_processor.py:9-57;
+ * models/neti_clip_text_encoder.py:57-225; models/net_clip_text_embedding.py:34-137;
+ * models/neti_mapper.py:165-197).  This header is the boundary we introduce *beneath* those
+ * protocols; each entry point names the reference call it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only: raw device pointers, sizes, strides (in ELEMENTS unless noted);
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - every function returns 0 on success or a negative VNETI_E* code; the message is
+ *     retrievable with vneti_last_error().  Nothing throws or aborts across the ABI.
+ *   - the library borrows pointers for the duration of the call only; it never allocates,
+ *     frees or synchronises, so every call is hipGraph-capturable.
+ *   - activations are channels-last: images are [B][H][W][C] f16, token matrices are
+ *     [rows][C]; "ld" is the row (pixel) stride in elements so tensors can be views into
+ *     wider buffers (this is how skip-connection concats are made free).
+ */
+#ifndef VNETI_H
+#define VNETI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VNETI_ABI_VERSION 1
+
+int vneti_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
+int vneti_last_error(char* buf, size_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM 3x3 convolution (MFMA).  C[M,N] = epi(alpha * A[M,K] . B[N,K]^T)
+ * Replaces: torch.nn.functional.conv2d / linear issued by diffusers' ResnetBlock2D,
+ * Downsample2D, Upsample2D, Transformer2DModel, CrossAttention.to_{q,k,v,out}
+ * (models/xti_attention_processor.py:30-42,53) and transformers' CLIPEncoder linears
+ * (models/neti_clip_text_encoder.py:111-118), forward and input-gradient.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vneti_gemm_desc {
+  const void* A;      /* f16: plain [M][lda] matrix, or NHWC image when conv_mode != 0 */
+  const void* B;      /* f16 weights, [N][ldb] with K contiguous ("NT" form) */
+  void* C;            /* f16 (or f32 when out_f32) [M][ldc] */
+  long long lda, ldb, ldc;
+  int M, N, K;        /* K % 64 == 0 */
+  int batch;          /* grid.y batches (0/1 = none) with element strides below */
+  long long strideA, strideB, strideC;
+  const float* bias;  /* f32 [N] or NULL, added before activation and rounding */
+  const void* rowadd; /* f16 [M / rows_per_group][ld_rowadd] or NULL: per-row-group broadcast add
+                         (ResnetBlock2D's "+ time_emb_proj(...)[:, :, None, None]") */
+  long long ld_rowadd;
+  int rows_per_group;
+  const void* resid;  /* same dtype/shape as C (row stride ldr) or NULL: fused residual add */
+  long long ldr;
+  float alpha;
+  int act;            /* 0 none, 1 SiLU, 2 quick-GELU, 3 exact GELU */
+  int out_f32;
+  /* implicit convolution: A is an NHWC image [Bn][Hi][Wi][ldx], K = 9*Ci ordered (tap, ci),
+     M = Bn*Ho*Wo.  conv_mode 1: forward gather  in(oy*stride+dy-pad_t, ox*stride+dx-pad_l),
+     optionally through a fused nearest-2x upsample (ups: Hi,Wi are the LOW-res dims);
+     conv_mode 2: transposed gather for dgrad  in((oy+pad_t-dy)/stride, (ox+pad_l-dx)/stride). */
+  int conv_mode;
+  int Hi, Wi, Ci, Ho, Wo, stride, pad_t, pad_l, ups;
+  long long ldx;
+  int tile_hint;      /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 64x64, 4: 256x128 tiles */
+} vneti_gemm_desc;
+
+int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream);
+
+/* 3x3 im2col for convolutions with tiny Cin (conv_in of UNet / VAE, dgrad of conv_out):
+ * out[m][tap*C + c] (f16, row length 64, zero padded) from an arbitrarily strided image.
+ * Replaces the first conv2d of diffusers' UNet2DConditionModel / AutoencoderKL encoder. */
+int vneti_im2col3x3_small(const void* x, int x_is_f32, long long sb, long long sc, long long sy,
+                          long long sx, void* out, int Bn, int C, int Hi, int Wi, int Ho, int Wo,
+                          int stride, int pad_t, int pad_l, void* stream);
+
+/* batched 2-D transpose of f16 matrices: out[b][c][r] = in[b][r][c]; columns of `out` in
+ * [rows, ld_out) are zero filled (attention kernels read K^T / V^T / Q^T / dO^T tiles). */
+int vneti_transpose_f16(const void* in, long long ld_in, long long stride_in, void* out,
+                        long long ld_out, long long stride_out, int rows, int cols, int batch,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU) on NHWC f16, statistics in f32.
+ * Replaces: diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm,
+ * conv_norm_out (driven from training/coach.py:197), forward and input-gradient.
+ * ws: f32 workspace of vneti_groupnorm_ws_floats(...) floats.
+ * ------------------------------------------------------------------------------------------ */
+long long vneti_groupnorm_ws_floats(int Bn, int HW, int C, int G);
+int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                        const float* beta, float* mean, float* rstd, float* ws, int Bn, int HW,
+                        int C, int G, float eps, int silu, void* stream);
+/* dx = d(loss)/d(x) given dy = d(loss)/d(y); y = silu?(GN(x)).  If dx_accum != NULL it is
+ * added (f16, row stride lddx) — used where two gradient paths meet. */
+int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x, long long ldx,
+                        const float* gamma, const float* beta, const float* mean,
+                        const float* rstd, void* dx, long long lddx, const void* dx_accum,
+                        long long ldacc, float* ws, int Bn, int HW, int C, int G, int silu,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim of [rows][C]; x is f16 or f32, y is f16.
+ * Replaces: BasicTransformerBlock.norm1/2/3 and CLIPEncoderLayer.layer_norm1/2,
+ * final_layer_norm (models/neti_clip_text_encoder.py:183-185).
+ * ------------------------------------------------------------------------------------------ */
+int vneti_layernorm_fwd(const void* x, int x_is_f32, long long ldx, void* y, long long ldy,
+                        const float* gamma, const float* beta, float* mean, float* rstd, int rows,
+                        int C, float eps, void* stream);
+/* dx (+= dx_accum) ; dx/dx_accum dtype selected by dx_is_f32 */
+int vneti_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, const void* x,
+                        int x_is_f32, long long ldx, const float* gamma, const float* mean,
+                        const float* rstd, void* dx, int dx_is_f32, long long lddx,
+                        const void* dx_accum, long long ldacc, int rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused (flash-style) multi-head attention, head_dim in {40, 64, 80, 160}.
+ *   O[b,q,h,:] = softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,:]
+ * Q/K/O rows are token rows of [B*N][ld] matrices with head h at column h*D.  V (and for
+ * the backward K, Q, dO) are additionally supplied TRANSPOSED per batch: Xt[b][h*D+d][n]
+ * with row stride ldt (>= N, multiple of 8, pad columns zero) — see vneti_transpose_f16.
+ * K and V come from separate tensors: this is the XTI contract
+ * (models/xti_attention_processor.py:38-42: key from CONTEXT_TENSOR_l, value from
+ * CONTEXT_TENSOR_BYPASS_l).  Replaces attn.get_attention_scores + torch.bmm (:48-49)
+ * without materialising the score matrix.  lse: f32 [B][H][Nq] (natural log).
+ * ------------------------------------------------------------------------------------------ */
+int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long long ldk, const void* Vt,
+                   long long ldvt, void* O, long long ldo, float* lse, int Bn, int H, int Nq,
+                   int Nk, int D, float scale, int causal, void* stream);
+/* delta[b][h][q] = sum_d dO*O  (f32) */
+int vneti_attn_bwd_delta(const void* dO, long long lddo, const void* O, long long ldo,
+                         float* delta, int Bn, int H, int Nq, int D, void* stream);
+int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, long long ldk, const void* Kt,
+                      long long ldkt, const void* V, long long ldv, const void* dO,
+                      long long lddo, const float* lse, const float* delta, void* dQ,
+                      long long lddq, int Bn, int H, int Nq, int Nk, int D, float scale,
+                      int causal, void* stream);
+int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, long long ldqt,
+                       const void* K, long long ldk, const void* V, long long ldv,
+                       const void* dO, long long lddo, const void* dOt, long long lddot,
+                       const float* lse, const float* delta, void* dK, long long lddk, void* dV,
+                       long long lddv, int Bn, int H, int Nq, int Nk, int D, float scale,
+                       int causal, void* stream);
+/* row softmax in place on f16 [rows][ld] (unfused attention of the VAE mid-block, d=512) */
+int vneti_softmax_rows_f16(void* x, long long ld, int rows, int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VNETI_H */

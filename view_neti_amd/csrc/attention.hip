@@ -1,0 +1,776 @@
+// Fused multi-head attention for gfx950: forward, dQ and dK/dV kernels on
+// v_mfma_f32_32x32x16_f16 with in-register online softmax.  No N x N score matrix ever
+// reaches HBM (the reference materialises it: models/xti_attention_processor.py:48-49).
+//
+// The XTI contract (models/xti_attention_processor.py:16-42) is native here: keys and values
+// are separate tensors (K from CONTEXT_TENSOR_l, V from CONTEXT_TENSOR_BYPASS_l), and the
+// backward returns dK and dV separately so they flow to the two context gradients.
+//
+// Operand orientation.  Scores are computed TRANSPOSED, S^T[key][q] = K.Q^T, so that in the
+// 32x32 MFMA accumulator layout (col = lane&31, rows = 8*(r>>2) + 4*(lane>>5) + (r&3)) every
+// lane owns one query column: row max / row sum are in-lane reductions plus one cross-half
+// shuffle.  The accumulator registers 8j..8j+7 of a lane are then *directly* the B operand
+// (k = 8 keys) of the second MFMA  O^T[d][q] += V^T[d][key] . P^T[key][q]  if the A operand
+// is gathered with the same key order, which needs V^T (d-major) in LDS — callers supply the
+// per-batch transposed copies (vneti_transpose_f16).  Head dims 40/80 are zero padded to the
+// MFMA k-step (16) for contractions over d and to 32 for output rows.
+#include "common.h"
+#include "../../include/vneti.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int TROW64 = 144;  // bytes per row of a [d][64 keys] transposed LDS tile (64*2 + 16 pad)
+constexpr int TROW32 = 80;   // bytes per row of a [d][32 q] transposed LDS tile (32*2 + 16 pad)
+
+template <int D>
+struct Cfg {
+  static constexpr int KS = (D + 15) / 16;   // k-steps when contracting over d
+  static constexpr int DPAD = KS * 16;
+  static constexpr int DB = (D + 31) / 32;   // 32-row output blocks over d
+  static constexpr int DCH = D / 8;          // valid 16-byte chunks per row
+  static constexpr int ROW = DPAD * 2 + 16;  // bytes per LDS row of a [n][d] tile (odd multiple of 16)
+};
+
+struct AttnArgs {
+  const half_t *Q, *K, *V, *Kt, *Vt, *Qt, *dO, *dOt;
+  half_t *O, *dQ, *dK, *dV;
+  float* lse;
+  const float* lse_in;
+  const float* delta;
+  long long ldq, ldk, ldv, ldkt, ldvt, ldqt, ldo, lddo, lddot, lddq, lddk, lddv;
+  int Bn, H, Nq, Nk, D;
+  float scale;
+  int causal;
+};
+
+__device__ __forceinline__ void zero_lds(char* smem, int bytes) {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  for (int i = threadIdx.x * 16; i < bytes; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = z;
+}
+
+__device__ __forceinline__ half8 cvt8(const f32x16& v, int j) {
+  half8 h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h[e] = (half_t)v[8 * j + e];
+  return h;
+}
+
+// A operand (rows = d, k-slots = the 8 keys/queries a lane owns) from a transposed LDS tile.
+__device__ __forceinline__ half8 load_tfrag(const char* base, int row_bytes, int d, int n0) {
+  const char* p = base + d * row_bytes + n0 * 2;
+  half4 lo = as_half4(*reinterpret_cast<const u32x2*>(p));
+  half4 hi = as_half4(*reinterpret_cast<const u32x2*>(p + 16));
+  half8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return r;
+}
+
+// ============================================================================================
+// forward
+// ============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  using C = Cfg<D>;
+  constexpr int KS_BYTES = 64 * C::ROW;
+  constexpr int VS_BYTES = C::DB * 32 * TROW64;
+  __shared__ __attribute__((aligned(16))) char smem[KS_BYTES + VS_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + KS_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qb0 = blockIdx.x * 128;
+  const int q = qb0 + wave * 32 + l31;
+  const bool qok = q < a.Nq;
+
+  __amdgpu_buffer_rsrc_t rsQ = vn_make_rsrc(a.Q, (uint32_t)((long long)a.Bn * a.Nq * a.ldq * 2));
+  __amdgpu_buffer_rsrc_t rsK = vn_make_rsrc(a.K, (uint32_t)((long long)a.Bn * a.Nk * a.ldk * 2));
+  __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.Vt, (uint32_t)((long long)a.Bn * a.H * D * a.ldvt * 2));
+
+  zero_lds(smem, KS_BYTES + VS_BYTES);
+
+  half8 qf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    int ch = ks * 2 + h2;
+    uint32_t off = (qok && ch < C::DCH)
+                       ? (uint32_t)((((long long)b * a.Nq + q) * a.ldq + h * D + ch * 8) * 2)
+                       : VN_OOB;
+    qf[ks] = as_half8(vn_buf_load16(rsQ, off));
+  }
+
+  constexpr int KIT = (64 * C::DCH + 255) / 256;
+  constexpr int VIT = (D * 8 + 255) / 256;
+  u32x4 kreg[KIT], vreg[VIT];
+
+  auto issue = [&](int kt) {
+    const int key0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      int idx = tid + 256 * i;
+      int r = idx / C::DCH, c = idx - r * C::DCH;
+      int key = key0 + r;
+      uint32_t off = (idx < 64 * C::DCH && key < a.Nk)
+                         ? (uint32_t)((((long long)b * a.Nk + key) * a.ldk + h * D + c * 8) * 2)
+                         : VN_OOB;
+      kreg[i] = vn_buf_load16(rsK, off);
+    }
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+      int idx = tid + 256 * i;
+      int d = idx >> 3, c = idx & 7;
+      int key = key0 + c * 8;
+      uint32_t off = (idx < D * 8 && key < a.ldvt)
+                         ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.ldvt + key) * 2)
+                         : VN_OOB;
+      vreg[i] = vn_buf_load16(rsV, off);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      int idx = tid + 256 * i;
+      int r = idx / C::DCH, c = idx - r * C::DCH;
+      if (idx < 64 * C::DCH) *reinterpret_cast<u32x4*>(Ks + r * C::ROW + c * 16) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+      int idx = tid + 256 * i;
+      int d = idx >> 3, c = idx & 7;
+      if (idx < D * 8) *reinterpret_cast<u32x4*>(Vs + d * TROW64 + c * 16) = vreg[i];
+    }
+  };
+
+  f32x16 o[C::DB];
+#pragma unroll
+  for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const float c = a.scale * LOG2E;
+
+  int nkt = cdiv_dev(a.Nk, 64);
+  if (a.causal) {
+    int lim = (min(qb0 + 127, a.Nq - 1)) / 64 + 1;
+    nkt = min(nkt, lim);
+  }
+
+  issue(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (kt + 1 < nkt) issue(kt + 1);
+    const int key0 = kt * 64;
+
+    f32x16 s[2];
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[aa][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        half8 kf = as_half8(
+            *reinterpret_cast<const u32x4*>(Ks + (aa * 32 + l31) * C::ROW + (ks * 2 + h2) * 16));
+        s[aa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[aa], 0, 0, 0);
+      }
+    }
+    const bool need_mask = (key0 + 64 > a.Nk) || a.causal;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (need_mask) {
+          int key = key0 + aa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          bool ok = key < a.Nk && (!a.causal || key <= q);
+          if (!ok) s[aa][r] = -INFINITY;
+        }
+        mx = fmaxf(mx, s[aa][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f((m - m_use) * c);
+    const float mc = m_use * c;
+    float psum = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = exp2f(s[aa][r] * c - mc);
+        s[aa][r] = p;
+        psum += p;
+      }
+    }
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        half8 pf = cvt8(s[aa], j);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+          half8 vf = load_tfrag(Vs, TROW64, db * 32 + l31, aa * 32 + 16 * j + 4 * h2);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  l += __shfl_xor(l, 32, 64);
+  const float inv = (l > 0.f) ? 1.f / l : 0.f;
+  if (qok) {
+    half_t* orow = a.O + ((long long)b * a.Nq + q) * a.ldo + h * D;
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        int d = db * 32 + 8 * qd + 4 * h2;
+        if (d < D) {
+          half4 v = {(half_t)(o[db][4 * qd] * inv), (half_t)(o[db][4 * qd + 1] * inv),
+                     (half_t)(o[db][4 * qd + 2] * inv), (half_t)(o[db][4 * qd + 3] * inv)};
+          *reinterpret_cast<half4*>(orow + d) = v;
+        }
+      }
+    }
+    if (h2 == 0 && a.lse) a.lse[((long long)b * a.H + h) * a.Nq + q] = m * a.scale + logf(l);
+  }
+}
+
+// ============================================================================================
+// backward: delta[b][h][q] = sum_d dO * O
+// ============================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restrict__ dO, long long lddo,
+                                                         const half_t* __restrict__ O, long long ldo,
+                                                         float* __restrict__ delta, int Bn, int H, int Nq,
+                                                         int D) {
+  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)Bn * Nq * H;
+  if (gid >= total) return;
+  int h = (int)(gid % H);
+  long long row = gid / H;  // b*Nq + q
+  const half_t* po = O + row * ldo + h * D;
+  const half_t* pd = dO + row * lddo + h * D;
+  float s = 0.f;
+  for (int c = 0; c < D; c += 8) {
+    half8 x = *reinterpret_cast<const half8*>(po + c);
+    half8 y = *reinterpret_cast<const half8*>(pd + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)x[j] * (float)y[j];
+  }
+  int b = (int)(row / Nq), q = (int)(row - (long long)b * Nq);
+  delta[((long long)b * H + h) * Nq + q] = s;
+}
+
+// ============================================================================================
+// backward: dQ.   per q-block of 128 (4 waves x 32 q), loop over 64-key tiles.
+//   S^T = K.Q^T ; P^T = exp(S^T*scale - lse) ; dP^T = V.dO^T ; dS^T = P^T o (dP^T - delta)
+//   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+// ============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_dq_kernel(AttnArgs a) {
+  using C = Cfg<D>;
+  constexpr int KS_BYTES = 64 * C::ROW;
+  constexpr int KT_BYTES = C::DB * 32 * TROW64;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KS_BYTES + KT_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + KS_BYTES;
+  char* Kts = smem + 2 * KS_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qb0 = blockIdx.x * 128;
+  const int q = qb0 + wave * 32 + l31;
+  const bool qok = q < a.Nq;
+
+  __amdgpu_buffer_rsrc_t rsQ = vn_make_rsrc(a.Q, (uint32_t)((long long)a.Bn * a.Nq * a.ldq * 2));
+  __amdgpu_buffer_rsrc_t rsdO = vn_make_rsrc(a.dO, (uint32_t)((long long)a.Bn * a.Nq * a.lddo * 2));
+  __amdgpu_buffer_rsrc_t rsK = vn_make_rsrc(a.K, (uint32_t)((long long)a.Bn * a.Nk * a.ldk * 2));
+  __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.V, (uint32_t)((long long)a.Bn * a.Nk * a.ldv * 2));
+  __amdgpu_buffer_rsrc_t rsKt = vn_make_rsrc(a.Kt, (uint32_t)((long long)a.Bn * a.H * D * a.ldkt * 2));
+
+  zero_lds(smem, 2 * KS_BYTES + KT_BYTES);
+
+  half8 qf[C::KS], dof[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    int ch = ks * 2 + h2;
+    bool ok = qok && ch < C::DCH;
+    uint32_t offq = ok ? (uint32_t)((((long long)b * a.Nq + q) * a.ldq + h * D + ch * 8) * 2) : VN_OOB;
+    uint32_t offd = ok ? (uint32_t)((((long long)b * a.Nq + q) * a.lddo + h * D + ch * 8) * 2) : VN_OOB;
+    qf[ks] = as_half8(vn_buf_load16(rsQ, offq));
+    dof[ks] = as_half8(vn_buf_load16(rsdO, offd));
+  }
+  const float c = a.scale * LOG2E;
+  float lse2 = INFINITY, dlt = 0.f;
+  if (qok) {
+    lse2 = a.lse_in[((long long)b * a.H + h) * a.Nq + q] * LOG2E;
+    dlt = a.delta[((long long)b * a.H + h) * a.Nq + q];
+  }
+
+  constexpr int KIT = (64 * C::DCH + 255) / 256;
+  constexpr int TIT = (D * 8 + 255) / 256;
+  u32x4 kreg[KIT], vreg[KIT], treg[TIT];
+
+  auto issue = [&](int kt) {
+    const int key0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      int idx = tid + 256 * i;
+      int r = idx / C::DCH, cc = idx - r * C::DCH;
+      int key = key0 + r;
+      bool ok = idx < 64 * C::DCH && key < a.Nk;
+      uint32_t offk = ok ? (uint32_t)((((long long)b * a.Nk + key) * a.ldk + h * D + cc * 8) * 2) : VN_OOB;
+      uint32_t offv = ok ? (uint32_t)((((long long)b * a.Nk + key) * a.ldv + h * D + cc * 8) * 2) : VN_OOB;
+      kreg[i] = vn_buf_load16(rsK, offk);
+      vreg[i] = vn_buf_load16(rsV, offv);
+    }
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+      int idx = tid + 256 * i;
+      int d = idx >> 3, cc = idx & 7;
+      int key = key0 + cc * 8;
+      uint32_t off = (idx < D * 8 && key < a.ldkt)
+                         ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.ldkt + key) * 2)
+                         : VN_OOB;
+      treg[i] = vn_buf_load16(rsKt, off);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+      int idx = tid + 256 * i;
+      int r = idx / C::DCH, cc = idx - r * C::DCH;
+      if (idx < 64 * C::DCH) {
+        *reinterpret_cast<u32x4*>(Ks + r * C::ROW + cc * 16) = kreg[i];
+        *reinterpret_cast<u32x4*>(Vs + r * C::ROW + cc * 16) = vreg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+      int idx = tid + 256 * i;
+      int d = idx >> 3, cc = idx & 7;
+      if (idx < D * 8) *reinterpret_cast<u32x4*>(Kts + d * TROW64 + cc * 16) = treg[i];
+    }
+  };
+
+  f32x16 dq[C::DB];
+#pragma unroll
+  for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
+
+  int nkt = cdiv_dev(a.Nk, 64);
+  if (a.causal) nkt = min(nkt, (min(qb0 + 127, a.Nq - 1)) / 64 + 1);
+
+  issue(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (kt + 1 < nkt) issue(kt + 1);
+    const int key0 = kt * 64;
+    const bool need_mask = (key0 + 64 > a.Nk) || a.causal;
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s[e] = 0.f;
+        dp[e] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const int off = (aa * 32 + l31) * C::ROW + (ks * 2 + h2) * 16;
+        half8 kf = as_half8(*reinterpret_cast<const u32x4*>(Ks + off));
+        half8 vf = as_half8(*reinterpret_cast<const u32x4*>(Vs + off));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = exp2f(s[r] * c - lse2);
+        if (need_mask) {
+          int key = key0 + aa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          bool ok = key < a.Nk && (!a.causal || key <= q);
+          if (!ok) p = 0.f;
+        }
+        s[r] = p * (dp[r] - dlt);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        half8 pf = cvt8(s, j);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+          half8 tf = load_tfrag(Kts, TROW64, db * 32 + l31, aa * 32 + 16 * j + 4 * h2);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, pf, dq[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (qok) {
+    half_t* orow = a.dQ + ((long long)b * a.Nq + q) * a.lddq + h * D;
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        int d = db * 32 + 8 * qd + 4 * h2;
+        if (d < D) {
+          half4 v = {(half_t)(dq[db][4 * qd] * a.scale), (half_t)(dq[db][4 * qd + 1] * a.scale),
+                     (half_t)(dq[db][4 * qd + 2] * a.scale), (half_t)(dq[db][4 * qd + 3] * a.scale)};
+          *reinterpret_cast<half4*>(orow + d) = v;
+        }
+      }
+    }
+  }
+}
+
+// ============================================================================================
+// backward: dK, dV.   per key-block of 128 (4 waves x 32 keys), loop over 32-query tiles.
+//   S[q][key] = Q.K^T ; P = exp(S*scale - lse) ; dP = dO.V^T ; dS = P o (dP - delta)
+//   dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+// ============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
+  using C = Cfg<D>;
+  constexpr int QS_BYTES = 32 * C::ROW;
+  constexpr int QT_BYTES = C::DB * 32 * TROW32;
+  __shared__ __attribute__((aligned(16))) char smem[2 * QS_BYTES + 2 * QT_BYTES + 256];
+  char* Qs = smem;
+  char* dOs = smem + QS_BYTES;
+  char* Qts = smem + 2 * QS_BYTES;
+  char* dOts = Qts + QT_BYTES;
+  float* lses = reinterpret_cast<float*>(dOts + QT_BYTES);
+  float* dels = lses + 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kb0 = blockIdx.x * 128;
+  const int key = kb0 + wave * 32 + l31;
+  const bool kok = key < a.Nk;
+
+  __amdgpu_buffer_rsrc_t rsQ = vn_make_rsrc(a.Q, (uint32_t)((long long)a.Bn * a.Nq * a.ldq * 2));
+  __amdgpu_buffer_rsrc_t rsdO = vn_make_rsrc(a.dO, (uint32_t)((long long)a.Bn * a.Nq * a.lddo * 2));
+  __amdgpu_buffer_rsrc_t rsK = vn_make_rsrc(a.K, (uint32_t)((long long)a.Bn * a.Nk * a.ldk * 2));
+  __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.V, (uint32_t)((long long)a.Bn * a.Nk * a.ldv * 2));
+  __amdgpu_buffer_rsrc_t rsQt = vn_make_rsrc(a.Qt, (uint32_t)((long long)a.Bn * a.H * D * a.ldqt * 2));
+  __amdgpu_buffer_rsrc_t rsdOt = vn_make_rsrc(a.dOt, (uint32_t)((long long)a.Bn * a.H * D * a.lddot * 2));
+
+  zero_lds(smem, 2 * QS_BYTES + 2 * QT_BYTES + 256);
+
+  half8 kf[C::KS], vf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    int ch = ks * 2 + h2;
+    bool ok = kok && ch < C::DCH;
+    uint32_t offk = ok ? (uint32_t)((((long long)b * a.Nk + key) * a.ldk + h * D + ch * 8) * 2) : VN_OOB;
+    uint32_t offv = ok ? (uint32_t)((((long long)b * a.Nk + key) * a.ldv + h * D + ch * 8) * 2) : VN_OOB;
+    kf[ks] = as_half8(vn_buf_load16(rsK, offk));
+    vf[ks] = as_half8(vn_buf_load16(rsV, offv));
+  }
+  const float c = a.scale * LOG2E;
+
+  constexpr int QIT = (32 * C::DCH + 255) / 256;
+  constexpr int TIT = (D * 4 + 255) / 256;
+  u32x4 qreg[QIT], doreg[QIT], qtreg[TIT], dotreg[TIT];
+  float lreg = INFINITY, dreg = 0.f;
+
+  auto issue = [&](int qt) {
+    const int q0 = qt * 32;
+#pragma unroll
+    for (int i = 0; i < QIT; ++i) {
+      int idx = tid + 256 * i;
+      int r = idx / C::DCH, cc = idx - r * C::DCH;
+      int qq = q0 + r;
+      bool ok = idx < 32 * C::DCH && qq < a.Nq;
+      uint32_t o1 = ok ? (uint32_t)((((long long)b * a.Nq + qq) * a.ldq + h * D + cc * 8) * 2) : VN_OOB;
+      uint32_t o2 = ok ? (uint32_t)((((long long)b * a.Nq + qq) * a.lddo + h * D + cc * 8) * 2) : VN_OOB;
+      qreg[i] = vn_buf_load16(rsQ, o1);
+      doreg[i] = vn_buf_load16(rsdO, o2);
+    }
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+      int idx = tid + 256 * i;
+      int d = idx >> 2, cc = idx & 3;
+      int qq = q0 + cc * 8;
+      bool okr = idx < D * 4;
+      uint32_t o1 = (okr && qq < a.ldqt)
+                        ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.ldqt + qq) * 2)
+                        : VN_OOB;
+      uint32_t o2 = (okr && qq < a.lddot)
+                        ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.lddot + qq) * 2)
+                        : VN_OOB;
+      qtreg[i] = vn_buf_load16(rsQt, o1);
+      dotreg[i] = vn_buf_load16(rsdOt, o2);
+    }
+    if (tid < 32) {
+      int qq = q0 + tid;
+      if (qq < a.Nq) {
+        lreg = a.lse_in[((long long)b * a.H + h) * a.Nq + qq] * LOG2E;
+        dreg = a.delta[((long long)b * a.H + h) * a.Nq + qq];
+      } else {
+        lreg = INFINITY;
+        dreg = 0.f;
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < QIT; ++i) {
+      int idx = tid + 256 * i;
+      int r = idx / C::DCH, cc = idx - r * C::DCH;
+      if (idx < 32 * C::DCH) {
+        *reinterpret_cast<u32x4*>(Qs + r * C::ROW + cc * 16) = qreg[i];
+        *reinterpret_cast<u32x4*>(dOs + r * C::ROW + cc * 16) = doreg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+      int idx = tid + 256 * i;
+      int d = idx >> 2, cc = idx & 3;
+      if (idx < D * 4) {
+        *reinterpret_cast<u32x4*>(Qts + d * TROW32 + cc * 16) = qtreg[i];
+        *reinterpret_cast<u32x4*>(dOts + d * TROW32 + cc * 16) = dotreg[i];
+      }
+    }
+    if (tid < 32) {
+      lses[tid] = lreg;
+      dels[tid] = dreg;
+    }
+  };
+
+  f32x16 dk[C::DB], dv[C::DB];
+#pragma unroll
+  for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      dk[i][e] = 0.f;
+      dv[i][e] = 0.f;
+    }
+
+  const int nqt = cdiv_dev(a.Nq, 32);
+  const int qt0 = a.causal ? min(kb0 / 32, nqt) : 0;
+
+  if (qt0 < nqt) issue(qt0);
+  for (int qt = qt0; qt < nqt; ++qt) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (qt + 1 < nqt) issue(qt + 1);
+    const int q0 = qt * 32;
+
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s[e] = 0.f;
+      dp[e] = 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int off = l31 * C::ROW + (ks * 2 + h2) * 16;
+      half8 qfr = as_half8(*reinterpret_cast<const u32x4*>(Qs + off));
+      half8 dofr = as_half8(*reinterpret_cast<const u32x4*>(dOs + off));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dofr, vf[ks], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      f32x4 l4 = *reinterpret_cast<const f32x4*>(&lses[8 * qd + 4 * h2]);
+      f32x4 d4 = *reinterpret_cast<const f32x4*>(&dels[8 * qd + 4 * h2]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * qd + e;
+        float p = exp2f(s[r] * c - l4[e]);
+        if (a.causal) {
+          int qq = q0 + 8 * qd + 4 * h2 + e;
+          if (key > qq) p = 0.f;
+        }
+        s[r] = p;
+        dp[r] = p * (dp[r] - d4[e]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      half8 pf = cvt8(s, j);
+      half8 dsf = cvt8(dp, j);
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        half8 dot = load_tfrag(dOts, TROW32, db * 32 + l31, 16 * j + 4 * h2);
+        half8 qtf = load_tfrag(Qts, TROW32, db * 32 + l31, 16 * j + 4 * h2);
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf, dk[db], 0, 0, 0);
+      }
+    }
+  }
+
+  if (kok) {
+    half_t* krow = a.dK + ((long long)b * a.Nk + key) * a.lddk + h * D;
+    half_t* vrow = a.dV + ((long long)b * a.Nk + key) * a.lddv + h * D;
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        int d = db * 32 + 8 * qd + 4 * h2;
+        if (d < D) {
+          half4 k4 = {(half_t)(dk[db][4 * qd] * a.scale), (half_t)(dk[db][4 * qd + 1] * a.scale),
+                      (half_t)(dk[db][4 * qd + 2] * a.scale), (half_t)(dk[db][4 * qd + 3] * a.scale)};
+          half4 v4 = {(half_t)dv[db][4 * qd], (half_t)dv[db][4 * qd + 1], (half_t)dv[db][4 * qd + 2],
+                      (half_t)dv[db][4 * qd + 3]};
+          *reinterpret_cast<half4*>(krow + d) = k4;
+          *reinterpret_cast<half4*>(vrow + d) = v4;
+        }
+      }
+    }
+  }
+}
+
+int check_common(int Bn, int H, int Nq, int Nk, int D) {
+  if (Bn <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return -1;
+  if (!(D == 40 || D == 64 || D == 80 || D == 160)) return -2;
+  return 0;
+}
+
+#define DISPATCH_D(KERNEL, grid, st, args)                                                   \
+  switch (args.D) {                                                                          \
+    case 40: hipLaunchKernelGGL((KERNEL<40>), grid, dim3(256), 0, st, args); break;          \
+    case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, st, args); break;          \
+    case 80: hipLaunchKernelGGL((KERNEL<80>), grid, dim3(256), 0, st, args); break;          \
+    default: hipLaunchKernelGGL((KERNEL<160>), grid, dim3(256), 0, st, args); break;         \
+  }
+
+}  // namespace
+
+extern "C" int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long long ldk, const void* Vt,
+                              long long ldvt, void* O, long long ldo, float* lse, int Bn, int H, int Nq, int Nk,
+                              int D, float scale, int causal, void* stream) {
+  int rc = check_common(Bn, H, Nq, Nk, D);
+  VN_REQUIRE(rc == 0, "attn_fwd: unsupported shape B=%d H=%d Nq=%d Nk=%d D=%d", Bn, H, Nq, Nk, D);
+  VN_REQUIRE(Q && K && Vt && O, "attn_fwd: null pointer");
+  VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Nk, "attn_fwd: bad strides");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const half_t*)Q;
+  a.K = (const half_t*)K;
+  a.Vt = (const half_t*)Vt;
+  a.O = (half_t*)O;
+  a.lse = lse;
+  a.ldq = ldq;
+  a.ldk = ldk;
+  a.ldvt = ldvt;
+  a.ldo = ldo;
+  a.Bn = Bn;
+  a.H = H;
+  a.Nq = Nq;
+  a.Nk = Nk;
+  a.D = D;
+  a.scale = scale;
+  a.causal = causal;
+  dim3 grid(cdiv(Nq, 128), H, Bn);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_D(attn_fwd_kernel, grid, st, a);
+  return vneti_check_launch("attn_fwd");
+}
+
+extern "C" int vneti_attn_bwd_delta(const void* dO, long long lddo, const void* O, long long ldo, float* delta,
+                                    int Bn, int H, int Nq, int D, void* stream) {
+  VN_REQUIRE(dO && O && delta && Bn > 0 && H > 0 && Nq > 0 && D % 8 == 0, "attn_bwd_delta: bad arguments");
+  long long total = (long long)Bn * Nq * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)dO, lddo, (const half_t*)O, ldo, delta, Bn, H, Nq, D);
+  return vneti_check_launch("attn_bwd_delta");
+}
+
+extern "C" int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, long long ldk, const void* Kt,
+                                 long long ldkt, const void* V, long long ldv, const void* dO, long long lddo,
+                                 const float* lse, const float* delta, void* dQ, long long lddq, int Bn, int H,
+                                 int Nq, int Nk, int D, float scale, int causal, void* stream) {
+  int rc = check_common(Bn, H, Nq, Nk, D);
+  VN_REQUIRE(rc == 0, "attn_bwd_dq: unsupported shape B=%d H=%d Nq=%d Nk=%d D=%d", Bn, H, Nq, Nk, D);
+  VN_REQUIRE(Q && K && Kt && V && dO && lse && delta && dQ, "attn_bwd_dq: null pointer");
+  VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldkt % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 &&
+                 ldkt >= Nk,
+             "attn_bwd_dq: bad strides");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const half_t*)Q;
+  a.K = (const half_t*)K;
+  a.Kt = (const half_t*)Kt;
+  a.V = (const half_t*)V;
+  a.dO = (const half_t*)dO;
+  a.dQ = (half_t*)dQ;
+  a.lse_in = lse;
+  a.delta = delta;
+  a.ldq = ldq;
+  a.ldk = ldk;
+  a.ldkt = ldkt;
+  a.ldv = ldv;
+  a.lddo = lddo;
+  a.lddq = lddq;
+  a.Bn = Bn;
+  a.H = H;
+  a.Nq = Nq;
+  a.Nk = Nk;
+  a.D = D;
+  a.scale = scale;
+  a.causal = causal;
+  dim3 grid(cdiv(Nq, 128), H, Bn);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_D(attn_dq_kernel, grid, st, a);
+  return vneti_check_launch("attn_bwd_dq");
+}
+
+extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, long long ldqt, const void* K,
+                                  long long ldk, const void* V, long long ldv, const void* dO, long long lddo,
+                                  const void* dOt, long long lddot, const float* lse, const float* delta,
+                                  void* dK, long long lddk, void* dV, long long lddv, int Bn, int H, int Nq,
+                                  int Nk, int D, float scale, int causal, void* stream) {
+  int rc = check_common(Bn, H, Nq, Nk, D);
+  VN_REQUIRE(rc == 0, "attn_bwd_dkv: unsupported shape B=%d H=%d Nq=%d Nk=%d D=%d", Bn, H, Nq, Nk, D);
+  VN_REQUIRE(Q && Qt && K && V && dO && dOt && lse && delta && dK && dV, "attn_bwd_dkv: null pointer");
+  VN_REQUIRE(ldq % 8 == 0 && ldqt % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddot % 8 == 0 &&
+                 lddk % 4 == 0 && lddv % 4 == 0 && ldqt >= Nq && lddot >= Nq,
+             "attn_bwd_dkv: bad strides");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const half_t*)Q;
+  a.Qt = (const half_t*)Qt;
+  a.K = (const half_t*)K;
+  a.V = (const half_t*)V;
+  a.dO = (const half_t*)dO;
+  a.dOt = (const half_t*)dOt;
+  a.dK = (half_t*)dK;
+  a.dV = (half_t*)dV;
+  a.lse_in = lse;
+  a.delta = delta;
+  a.ldq = ldq;
+  a.ldqt = ldqt;
+  a.ldk = ldk;
+  a.ldv = ldv;
+  a.lddo = lddo;
+  a.lddot = lddot;
+  a.lddk = lddk;
+  a.lddv = lddv;
+  a.Bn = Bn;
+  a.H = H;
+  a.Nq = Nq;
+  a.Nk = Nk;
+  a.D = D;
+  a.scale = scale;
+  a.causal = causal;
+  dim3 grid(cdiv(Nk, 128), H, Bn);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_D(attn_dkv_kernel, grid, st, a);
+  return vneti_check_launch("attn_bwd_dkv");
+}

@@ -1,0 +1,559 @@
+// GroupNorm(+SiLU) on channels-last f16 and LayerNorm, forward and input-gradient.
+// HBM-bound kernels: 16-byte loads/stores, f32 statistics, deterministic two-level reductions.
+//
+// Reference call sites: diffusers ResnetBlock2D.norm1/norm2 + SiLU, Transformer2DModel.norm,
+// conv_norm_out, BasicTransformerBlock.norm1..3 (all inside `self.unet(...)`,
+// training/coach.py:197-198) and CLIPEncoderLayer.layer_norm1/2 + final_layer_norm
+// (models/neti_clip_text_encoder.py:111-118,183-185).
+#include "common.h"
+#include "../../include/vneti.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm.  x: [B][HW][ldx] with C channels, G groups, cpg = C/G >= 4.
+// Work decomposition: block (slab, b) owns `rps` consecutive pixels of sample b.  Thread
+// (tx, ty) owns 8-channel chunk `tx` (looping in steps of TX when C/8 > 256) and walks rows
+// ty, ty+TY, ...  A chunk touches at most two groups ("lo"/"hi").
+// Pass 1 writes per-slab partial sums; pass 2 (one block per sample) finalises mean/rstd in
+// f64; pass 3 applies.  The backward has the same three-pass shape.
+// ------------------------------------------------------------------------------------------
+struct GNGeom {
+  int Bn, HW, C, G, cpg, CC, TX, TY, rps, nslab;
+};
+
+__device__ __forceinline__ void gn_thread_coords(const GNGeom& g, int& tx, int& ty, bool& active) {
+  int tid = threadIdx.x;
+  tx = tid % g.TX;
+  ty = tid / g.TX;
+  active = ty < g.TY;
+}
+
+template <bool BWD, bool SILU>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GNGeom g, const half_t* __restrict__ x, long long ldx,
+                                                       const half_t* __restrict__ dy, long long lddy,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd,
+                                                       float* __restrict__ part) {
+  __shared__ float gacc[2 * 64 * 2];  // [G<=64][2]
+  const int slab = blockIdx.x, b = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * g.G; i += 256) gacc[i] = 0.f;
+  __syncthreads();
+  int tx, ty;
+  bool active;
+  gn_thread_coords(g, tx, ty, active);
+  const int r0 = slab * g.rps;
+  const int r1 = min(r0 + g.rps, g.HW);
+  if (active) {
+    for (int cb = 0; cb < g.CC; cb += g.TX) {
+      const int cx = cb + tx;
+      if (cx >= g.CC) break;
+      const int ch0 = cx * 8;
+      const int g0 = ch0 / g.cpg;
+      const int split = (g0 + 1) * g.cpg - ch0;  // elements [0,split) belong to g0, rest to g0+1
+      float ga[8], be[8];
+      float mlo = 0.f, rlo = 0.f, mhi = 0.f, rhi = 0.f;
+      if (BWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ga[j] = gamma[ch0 + j];
+          be[j] = beta[ch0 + j];
+        }
+        mlo = mean[b * g.G + g0];
+        rlo = rstd[b * g.G + g0];
+        if (split < 8) {
+          mhi = mean[b * g.G + g0 + 1];
+          rhi = rstd[b * g.G + g0 + 1];
+        }
+      }
+      float a_lo = 0.f, b_lo = 0.f, a_hi = 0.f, b_hi = 0.f;
+      for (int r = r0 + ty; r < r1; r += g.TY) {
+        const long long row = (long long)b * g.HW + r;
+        half8 xv = *reinterpret_cast<const half8*>(x + row * ldx + ch0);
+        if (!BWD) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = (float)xv[j];
+            if (j < split) {
+              a_lo += v;
+              b_lo += v * v;
+            } else {
+              a_hi += v;
+              b_hi += v * v;
+            }
+          }
+        } else {
+          half8 dv = *reinterpret_cast<const half8*>(dy + row * lddy + ch0);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool lo = j < split;
+            float xh = ((float)xv[j] - (lo ? mlo : mhi)) * (lo ? rlo : rhi);
+            float d = (float)dv[j];
+            if (SILU) {
+              float z = xh * ga[j] + be[j];
+              float s = vn_sigmoid(z);
+              d *= s * (1.f + z * (1.f - s));
+            }
+            float dxh = d * ga[j];
+            if (lo) {
+              a_lo += dxh;
+              b_lo += dxh * xh;
+            } else {
+              a_hi += dxh;
+              b_hi += dxh * xh;
+            }
+          }
+        }
+      }
+      atomicAdd(&gacc[2 * g0], a_lo);
+      atomicAdd(&gacc[2 * g0 + 1], b_lo);
+      if (split < 8) {
+        atomicAdd(&gacc[2 * (g0 + 1)], a_hi);
+        atomicAdd(&gacc[2 * (g0 + 1) + 1], b_hi);
+      }
+    }
+  }
+  __syncthreads();
+  float* p = part + ((long long)b * g.nslab + slab) * (2 * g.G);
+  for (int i = threadIdx.x; i < 2 * g.G; i += 256) p[i] = gacc[i];
+}
+
+// one block per sample: reduce the slab partials.  FWD: -> mean, rstd.  BWD: -> (S1/n, S2/n).
+template <bool BWD>
+__global__ __launch_bounds__(64) void gn_finalize_kernel(GNGeom g, const float* __restrict__ part, float eps,
+                                                         float* __restrict__ o0, float* __restrict__ o1) {
+  const int b = blockIdx.x;
+  for (int gi = threadIdx.x; gi < g.G; gi += 64) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = 0; s < g.nslab; ++s) {
+      const float* p = part + ((long long)b * g.nslab + s) * (2 * g.G) + 2 * gi;
+      s0 += (double)p[0];
+      s1 += (double)p[1];
+    }
+    const double n = (double)g.HW * g.cpg;
+    if (!BWD) {
+      double m = s0 / n;
+      double var = s1 / n - m * m;
+      if (var < 0.0) var = 0.0;
+      o0[b * g.G + gi] = (float)m;
+      o1[b * g.G + gi] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      o0[b * g.G + gi] = (float)(s0 / n);
+      o1[b * g.G + gi] = (float)(s1 / n);
+    }
+  }
+}
+
+template <bool BWD, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* __restrict__ x, long long ldx,
+                                                       const half_t* __restrict__ dy, long long lddy,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd,
+                                                       const float* __restrict__ c1, const float* __restrict__ c2,
+                                                       half_t* __restrict__ out, long long ldo,
+                                                       const half_t* __restrict__ accum, long long ldacc) {
+  const int slab = blockIdx.x, b = blockIdx.y;
+  int tx, ty;
+  bool active;
+  gn_thread_coords(g, tx, ty, active);
+  if (!active) return;
+  const int r0 = slab * g.rps;
+  const int r1 = min(r0 + g.rps, g.HW);
+  for (int cb = 0; cb < g.CC; cb += g.TX) {
+    const int cx = cb + tx;
+    if (cx >= g.CC) break;
+    const int ch0 = cx * 8;
+    const int g0 = ch0 / g.cpg;
+    const int split = (g0 + 1) * g.cpg - ch0;
+    const int g1 = (split < 8) ? g0 + 1 : g0;
+    float ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ga[j] = gamma[ch0 + j];
+      be[j] = beta[ch0 + j];
+    }
+    const float mlo = mean[b * g.G + g0], rlo = rstd[b * g.G + g0];
+    const float mhi = mean[b * g.G + g1], rhi = rstd[b * g.G + g1];
+    float c1lo = 0.f, c2lo = 0.f, c1hi = 0.f, c2hi = 0.f;
+    if (BWD) {
+      c1lo = c1[b * g.G + g0];
+      c2lo = c2[b * g.G + g0];
+      c1hi = c1[b * g.G + g1];
+      c2hi = c2[b * g.G + g1];
+    }
+    for (int r = r0 + ty; r < r1; r += g.TY) {
+      const long long row = (long long)b * g.HW + r;
+      half8 xv = *reinterpret_cast<const half8*>(x + row * ldx + ch0);
+      half8 ov;
+      if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool lo = j < split;
+          float xh = ((float)xv[j] - (lo ? mlo : mhi)) * (lo ? rlo : rhi);
+          float z = xh * ga[j] + be[j];
+          if (SILU) z = vn_silu(z);
+          ov[j] = (half_t)z;
+        }
+      } else {
+        half8 dv = *reinterpret_cast<const half8*>(dy + row * lddy + ch0);
+        half8 av;
+        if (accum) av = *reinterpret_cast<const half8*>(accum + row * ldacc + ch0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool lo = j < split;
+          const float rs = lo ? rlo : rhi;
+          float xh = ((float)xv[j] - (lo ? mlo : mhi)) * rs;
+          float d = (float)dv[j];
+          if (SILU) {
+            float z = xh * ga[j] + be[j];
+            float s = vn_sigmoid(z);
+            d *= s * (1.f + z * (1.f - s));
+          }
+          float dxh = d * ga[j];
+          float dx = rs * (dxh - (lo ? c1lo : c1hi) - xh * (lo ? c2lo : c2hi));
+          if (accum) dx += (float)av[j];
+          ov[j] = (half_t)dx;
+        }
+      }
+      *reinterpret_cast<half8*>(out + row * ldo + ch0) = ov;
+    }
+  }
+}
+
+int gn_geom(GNGeom& g, int Bn, int HW, int C, int G) {
+  if (Bn <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || C % G != 0 || C % 8 != 0) return -1;
+  g.Bn = Bn;
+  g.HW = HW;
+  g.C = C;
+  g.G = G;
+  g.cpg = C / G;
+  if (g.cpg < 4) return -1;
+  g.CC = C / 8;
+  g.TX = g.CC < 256 ? g.CC : 256;
+  g.TY = 256 / g.TX;
+  int rps = 8192 / C;
+  if (rps < 1) rps = 1;
+  rps = ((rps + g.TY - 1) / g.TY) * g.TY;
+  int nslab = (HW + rps - 1) / rps;
+  while (nslab > 256) {
+    rps *= 2;
+    nslab = (HW + rps - 1) / rps;
+  }
+  g.rps = rps;
+  g.nslab = nslab;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, up to 4 chunks of 8 elements per lane (C <= 2048).
+// ------------------------------------------------------------------------------------------
+template <bool XF32>
+__device__ __forceinline__ void ln_load(const void* x, long long off, float v[8]) {
+  if (XF32) {
+    const float* p = reinterpret_cast<const float*>(x) + off;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = a[j];
+      v[4 + j] = b[j];
+    }
+  } else {
+    half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(x) + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void ln_store(void* y, long long off, const float v[8]) {
+  if (F32) {
+    float* p = reinterpret_cast<float*>(y) + off;
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  } else {
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(y) + off) = h;
+  }
+}
+
+constexpr int LN_MAXC = 4;
+
+template <bool XF32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, long long ldx,
+                                                     half_t* __restrict__ y, long long ldy,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int rows, int C, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int CC = C / 8;
+  float v[LN_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    int c = lane + 64 * i;
+    if (c < CC) {
+      ln_load<XF32>(x, (long long)row * ldx + c * 8, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  s = wave_sum(s);
+  const float m = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    int c = lane + 64 * i;
+    if (c < CC) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = v[i][j] - m;
+        q += d * d;
+      }
+    }
+  }
+  q = wave_sum(q);
+  const float rs = rsqrtf(q / (float)C + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = m;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    int c = lane + 64 * i;
+    if (c < CC) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - m) * rs * gamma[c * 8 + j] + beta[c * 8 + j];
+      ln_store<false>(y, (long long)row * ldy + c * 8, o);
+    }
+  }
+}
+
+template <bool DYF32, bool XF32, bool DXF32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long long lddy,
+                                                     const void* __restrict__ x, long long ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, void* __restrict__ dx,
+                                                     long long lddx, const void* __restrict__ accum,
+                                                     long long ldacc, int rows, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int CC = C / 8;
+  const float m = mean[row], rs = rstd[row];
+  float xh[LN_MAXC][8], dh[LN_MAXC][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    int c = lane + 64 * i;
+    if (c < CC) {
+      float xv[8], dv[8];
+      ln_load<XF32>(x, (long long)row * ldx + c * 8, xv);
+      ln_load<DYF32>(dy, (long long)row * lddy + c * 8, dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[i][j] = (xv[j] - m) * rs;
+        dh[i][j] = dv[j] * gamma[c * 8 + j];
+        s1 += dh[i][j];
+        s2 += dh[i][j] * xh[i][j];
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    int c = lane + 64 * i;
+    if (c < CC) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rs * (dh[i][j] - s1 - xh[i][j] * s2);
+      if (accum) {
+        float a[8];
+        ln_load<DXF32>(accum, (long long)row * ldacc + c * 8, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += a[j];
+      }
+      ln_store<DXF32>(dx, (long long)row * lddx + c * 8, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// in-place row softmax on f16 (VAE mid-block attention, N = H*W keys, single head d=512)
+// ------------------------------------------------------------------------------------------
+constexpr int SM_MAXC = 8;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ x, long long ld, int cols) {
+  __shared__ float red[4];
+  half_t* p = x + (long long)blockIdx.x * ld;
+  const int CC = cols / 8;
+  float v[SM_MAXC][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SM_MAXC; ++i) {
+    int c = threadIdx.x + 256 * i;
+    if (c < CC) {
+      half8 h = *reinterpret_cast<const half8*>(p + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[i][j] = (float)h[j];
+        mx = fmaxf(mx, v[i][j]);
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXC; ++i) {
+    int c = threadIdx.x + 256 * i;
+    if (c < CC) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[i][j] = __expf(v[i][j] - mx);
+        s += v[i][j];
+      }
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int i = 0; i < SM_MAXC; ++i) {
+    int c = threadIdx.x + 256 * i;
+    if (c < CC) {
+      half8 h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (half_t)(v[i][j] * inv);
+      *reinterpret_cast<half8*>(p + c * 8) = h;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" long long vneti_groupnorm_ws_floats(int Bn, int HW, int C, int G) {
+  GNGeom g;
+  if (gn_geom(g, Bn, HW, C, G) != 0) return -1;
+  // slab partials + (c1, c2) for the backward
+  return (long long)Bn * g.nslab * 2 * G + 2LL * Bn * G;
+}
+
+extern "C" int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                                   const float* beta, float* mean, float* rstd, float* ws, int Bn, int HW,
+                                   int C, int G, float eps, int silu, void* stream) {
+  GNGeom g;
+  VN_REQUIRE(gn_geom(g, Bn, HW, C, G) == 0, "groupnorm: unsupported shape B=%d HW=%d C=%d G=%d", Bn, HW, C, G);
+  VN_REQUIRE(x && y && gamma && beta && mean && rstd && ws, "groupnorm_fwd: null pointer");
+  VN_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "groupnorm_fwd: ld must be a multiple of 8");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(g.nslab, Bn);
+  hipLaunchKernelGGL((gn_stats_kernel<false, false>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                     (const half_t*)nullptr, 0LL, gamma, beta, (const float*)nullptr, (const float*)nullptr, ws);
+  hipLaunchKernelGGL((gn_finalize_kernel<false>), dim3(Bn), dim3(64), 0, st, g, (const float*)ws, eps, mean, rstd);
+  if (silu)
+    hipLaunchKernelGGL((gn_apply_kernel<false, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                       (const half_t*)nullptr, 0LL, gamma, beta, (const float*)mean, (const float*)rstd,
+                       (const float*)nullptr, (const float*)nullptr, (half_t*)y, ldy, (const half_t*)nullptr, 0LL);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<false, false>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                       (const half_t*)nullptr, 0LL, gamma, beta, (const float*)mean, (const float*)rstd,
+                       (const float*)nullptr, (const float*)nullptr, (half_t*)y, ldy, (const half_t*)nullptr, 0LL);
+  return vneti_check_launch("groupnorm_fwd");
+}
+
+extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x, long long ldx,
+                                   const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                   void* dx, long long lddx, const void* dx_accum, long long ldacc, float* ws,
+                                   int Bn, int HW, int C, int G, int silu, void* stream) {
+  GNGeom g;
+  VN_REQUIRE(gn_geom(g, Bn, HW, C, G) == 0, "groupnorm: unsupported shape B=%d HW=%d C=%d G=%d", Bn, HW, C, G);
+  VN_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && ws, "groupnorm_bwd: null pointer");
+  VN_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldacc % 8 == 0, "groupnorm_bwd: ld % 8 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(g.nslab, Bn);
+  float* c1 = ws + (long long)Bn * g.nslab * 2 * G;
+  float* c2 = c1 + (long long)Bn * G;
+  if (silu)
+    hipLaunchKernelGGL((gn_stats_kernel<true, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                       (const half_t*)dy, lddy, gamma, beta, mean, rstd, ws);
+  else
+    hipLaunchKernelGGL((gn_stats_kernel<true, false>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                       (const half_t*)dy, lddy, gamma, beta, mean, rstd, ws);
+  hipLaunchKernelGGL((gn_finalize_kernel<true>), dim3(Bn), dim3(64), 0, st, g, (const float*)ws, 0.f, c1, c2);
+  if (silu)
+    hipLaunchKernelGGL((gn_apply_kernel<true, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                       (const half_t*)dy, lddy, gamma, beta, mean, rstd, (const float*)c1, (const float*)c2,
+                       (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<true, false>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                       (const half_t*)dy, lddy, gamma, beta, mean, rstd, (const float*)c1, (const float*)c2,
+                       (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc);
+  return vneti_check_launch("groupnorm_bwd");
+}
+
+extern "C" int vneti_layernorm_fwd(const void* x, int x_is_f32, long long ldx, void* y, long long ldy,
+                                   const float* gamma, const float* beta, float* mean, float* rstd, int rows,
+                                   int C, float eps, void* stream) {
+  VN_REQUIRE(x && y && gamma && beta, "layernorm_fwd: null pointer");
+  VN_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXC, "layernorm: unsupported C=%d", C);
+  VN_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "layernorm_fwd: ld % 8 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(rows, 4));
+  if (x_is_f32)
+    hipLaunchKernelGGL((ln_fwd_kernel<true>), grid, dim3(256), 0, st, x, ldx, (half_t*)y, ldy, gamma, beta, mean,
+                       rstd, rows, C, eps);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<false>), grid, dim3(256), 0, st, x, ldx, (half_t*)y, ldy, gamma, beta, mean,
+                       rstd, rows, C, eps);
+  return vneti_check_launch("layernorm_fwd");
+}
+
+extern "C" int vneti_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, const void* x, int x_is_f32,
+                                   long long ldx, const float* gamma, const float* mean, const float* rstd,
+                                   void* dx, int dx_is_f32, long long lddx, const void* dx_accum, long long ldacc,
+                                   int rows, int C, void* stream) {
+  VN_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  VN_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXC, "layernorm: unsupported C=%d", C);
+  VN_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldacc % 8 == 0, "layernorm_bwd: ld % 8 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(rows, 4));
+#define LN_BWD(A, B, Cc)                                                                                          \
+  hipLaunchKernelGGL((ln_bwd_kernel<A, B, Cc>), grid, dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx, \
+                     lddx, dx_accum, ldacc, rows, C)
+  int key = (dy_is_f32 ? 4 : 0) | (x_is_f32 ? 2 : 0) | (dx_is_f32 ? 1 : 0);
+  switch (key) {
+    case 0: LN_BWD(false, false, false); break;
+    case 1: LN_BWD(false, false, true); break;
+    case 2: LN_BWD(false, true, false); break;
+    case 3: LN_BWD(false, true, true); break;
+    case 4: LN_BWD(true, false, false); break;
+    case 5: LN_BWD(true, false, true); break;
+    case 6: LN_BWD(true, true, false); break;
+    default: LN_BWD(true, true, true); break;
+  }
+#undef LN_BWD
+  return vneti_check_launch("layernorm_bwd");
+}
+
+extern "C" int vneti_softmax_rows_f16(void* x, long long ld, int rows, int cols, void* stream) {
+  VN_REQUIRE(x && rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 256 * SM_MAXC && ld % 8 == 0,
+             "softmax_rows: unsupported cols=%d ld=%lld", cols, ld);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, ld, cols);
+  return vneti_check_launch("softmax_rows");
+}
