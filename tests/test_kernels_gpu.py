@@ -1,0 +1,310 @@
+"""Per-kernel parity: each HIP kernel (through the C ABI) vs a plain PyTorch fp32 CPU reference
+computed from the SAME f16-rounded inputs.  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from view_neti_amd import ops
+    return ops
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def relerr(a, b):
+    a = a.float().cpu()
+    b = b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item(), (a - b).abs().max().item()
+
+
+def check(name, got, ref, tol):
+    r, m = relerr(got, ref)
+    print(f"[{name}] rel={r:.3e} maxabs={m:.3e}")
+    assert math.isfinite(r) and r < tol, f"{name}: rel err {r} (max abs {m}) >= {tol}"
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 128), (128, 64, 64), (77 * 4, 1280, 768), (1000, 8, 192)])
+def test_gemm_plain(hint, M, N, K):
+    ops = _ops()
+    A = rnd(M, K, seed=1)
+    B = rnd(N, K, scale=1.0 / math.sqrt(K), seed=2)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    res = rnd(M, N, seed=4)
+    ref = A.float() @ B.float().t() + bias
+    ref_h = ref.half().float() + res.float()
+    out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), tile_hint=hint)
+    torch.cuda.synchronize()
+    check(f"gemm {M}x{N}x{K} hint{hint}", out, ref_h, 2e-3)
+
+
+def test_gemm_transpose_detect_and_strides():
+    """asymmetric B and strided views (ld > cols) — catches swapped operand / layout bugs."""
+    ops = _ops()
+    M, N, K = 192, 136, 64
+    Abig = rnd(M, K + 64, seed=5).to(DEV)
+    A = Abig[:, 64:]
+    B = torch.zeros(N, K, dtype=torch.float16)
+    for n in range(N):
+        B[n, (n * 7) % K] = 1.0 + n / 64.0
+    outbig = torch.zeros(M, N + 24, dtype=torch.float16, device=DEV)
+    out = outbig[:, 8:8 + N]
+    ops.gemm(A, B.to(DEV), out, alpha=0.5)
+    torch.cuda.synchronize()
+    ref = 0.5 * (A.float().cpu() @ B.float().t())
+    check("gemm strided/asym", out, ref, 1e-3)
+    assert outbig[:, :8].abs().sum().item() == 0 and outbig[:, 8 + N:].abs().sum().item() == 0
+
+
+def test_gemm_f32_out_rowadd_act_batch():
+    ops = _ops()
+    M, N, K = 260, 192, 128
+    A = rnd(M, K, seed=6)
+    B = rnd(N, K, scale=1 / math.sqrt(K), seed=7)
+    res = rnd(M, N, seed=8, dtype=torch.float32)
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), out, resid=res.to(DEV))
+    torch.cuda.synchronize()
+    check("gemm f32out+resid", out, A.float() @ B.float().t() + res, 1e-3)
+    # rowadd (time-embedding broadcast) + SiLU epilogue, f16
+    rows_per_group = 65
+    radd = rnd(M // rows_per_group, N, seed=9)
+    out2 = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), out2, rowadd=radd.to(DEV), rows_per_group=rows_per_group, act=ops.ACT_SILU)
+    torch.cuda.synchronize()
+    ref = F.silu(A.float() @ B.float().t()).half().float() + radd.float().repeat_interleave(rows_per_group, 0)
+    check("gemm rowadd+silu", out2, ref, 2e-3)
+    # batched (grid.y) with shared B
+    Ab = rnd(3, 100, K, seed=10)
+    outb = torch.zeros(3, 100, N, dtype=torch.float16, device=DEV)
+    ops.gemm(Ab.to(DEV), B.to(DEV), outb, batch=3, strideA=100 * K, strideB=0, strideC=100 * N, M=100, lda=K, ldc=N)
+    torch.cuda.synchronize()
+    check("gemm batched", outb, Ab.float() @ B.float().t(), 2e-3)
+
+
+# ------------------------------------------------------------------------------------------ conv
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("case", ["s1", "s2p1", "s2vae", "ups"])
+@pytest.mark.parametrize("hint", [0, 1, 3])
+def test_conv3x3_fwd(case, hint):
+    ops = _ops()
+    from view_neti_amd import packing
+    Bn, Ci, Co, H, W = 2, 64, 128, 12, 20
+    x = rnd(Bn, Ci, H, W, seed=11)
+    w = rnd(Co, Ci, 3, 3, scale=1 / math.sqrt(9 * Ci), seed=12)
+    bias = rnd(Co, seed=13, dtype=torch.float32)
+    xf, wf = x.float(), w.float()
+    if case == "s1":
+        ref = F.conv2d(xf, wf, bias, padding=1)
+        conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci)
+    elif case == "s2p1":
+        ref = F.conv2d(xf, wf, bias, stride=2, padding=1)
+        conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H // 2, Wo=W // 2, stride=2, pad_t=1, pad_l=1, ups=0, ldx=Ci)
+    elif case == "s2vae":
+        ref = F.conv2d(F.pad(xf, (0, 1, 0, 1)), wf, bias, stride=2, padding=0)
+        conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H // 2, Wo=W // 2, stride=2, pad_t=0, pad_l=0, ups=0, ldx=Ci)
+    else:
+        ref = F.conv2d(F.interpolate(xf, scale_factor=2.0, mode="nearest"), wf, bias, padding=1)
+        conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=2 * H, Wo=2 * W, stride=1, pad_t=1, pad_l=1, ups=1, ldx=Ci)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = torch.zeros(Bn * Ho * Wo, Co, dtype=torch.float16, device=DEV)
+    ops.gemm(_nhwc(x).to(DEV), packing.conv3x3_fwd(w).to(DEV), out, bias=bias.to(DEV), conv=conv,
+             M=Bn * Ho * Wo, tile_hint=hint)
+    torch.cuda.synchronize()
+    check(f"conv {case} hint{hint}", out.view(Bn, Ho, Wo, Co), _nhwc(ref), 2e-3)
+
+
+@pytest.mark.parametrize("stride,vae", [(1, False), (2, False), (2, True)])
+def test_conv3x3_dgrad(stride, vae):
+    ops = _ops()
+    from view_neti_amd import packing
+    Bn, Ci, Co, H, W = 2, 64, 128, 12, 20
+    x = rnd(Bn, Ci, H, W, seed=14).float().requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, scale=1 / math.sqrt(9 * Ci), seed=15)
+    if vae:
+        y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w.float(), None, stride=2, padding=0)
+        pt = 0
+    else:
+        y = F.conv2d(x, w.float(), None, stride=stride, padding=1)
+        pt = 1
+    dy = rnd(*y.shape, seed=16)
+    y.backward(dy.float())
+    Ho, Wo = y.shape[2], y.shape[3]
+    dx = torch.zeros(Bn * H * W, Ci, dtype=torch.float16, device=DEV)
+    conv = dict(mode=2, Hi=Ho, Wi=Wo, Ci=Co, Ho=H, Wo=W, stride=stride, pad_t=pt, pad_l=pt, ups=0, ldx=Co)
+    ops.gemm(_nhwc(dy).to(DEV), packing.conv3x3_dgrad(w).to(DEV), dx, conv=conv, M=Bn * H * W)
+    torch.cuda.synchronize()
+    check(f"conv dgrad s{stride} vae={vae}", dx.view(Bn, H, W, Ci), _nhwc(x.grad), 2e-3)
+
+
+def test_im2col_small_and_conv_in():
+    ops = _ops()
+    from view_neti_amd import packing
+    Bn, Ci, Co, H, W = 2, 4, 64, 16, 16
+    x = rnd(Bn, Ci, H, W, seed=17, dtype=torch.float32)
+    w = rnd(Co, Ci, 3, 3, scale=0.2, seed=18)
+    col = torch.zeros(Bn * H * W, 64, dtype=torch.float16, device=DEV)
+    xd = x.to(DEV)
+    ops.im2col3x3_small(xd, col, Bn, Ci, H, W, H, W, 1, 1, 1, xd.stride())
+    wp = packing.pad_rows(packing.conv3x3_fwd(w), 64).to(DEV)
+    out = torch.zeros(Bn * H * W, Co, dtype=torch.float16, device=DEV)
+    ops.gemm(col, wp, out)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.half().float(), w.float(), None, padding=1)
+    check("conv_in via im2col", out.view(Bn, H, W, Co), _nhwc(ref), 2e-3)
+
+
+# ------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("Cc,HW", [(320, 256), (128, 1024), (2560, 64), (960, 100)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_fwd_bwd(Cc, HW, silu):
+    ops = _ops()
+    Bn, G, eps = 2, 32, 1e-5
+    x = (rnd(Bn, HW, Cc, seed=19).float() * 1.5 + 0.3).half()
+    gamma = 1 + 0.1 * rnd(Cc, seed=20, dtype=torch.float32)
+    beta = 0.1 * rnd(Cc, seed=21, dtype=torch.float32)
+    dy = rnd(Bn, HW, Cc, seed=22)
+    xr = x.float().permute(0, 2, 1).requires_grad_(True)  # [B, C, HW]
+    yr = F.group_norm(xr, G, gamma, beta, eps)
+    if silu:
+        yr = F.silu(yr)
+    yr.backward(dy.float().permute(0, 2, 1))
+    xd = x.to(DEV).view(Bn * HW, Cc)
+    y = torch.zeros_like(xd)
+    mean = torch.zeros(Bn * G, dtype=torch.float32, device=DEV)
+    rstd = torch.zeros_like(mean)
+    ws = torch.zeros(ops.groupnorm_ws_floats(Bn, HW, Cc, G), dtype=torch.float32, device=DEV)
+    ops.groupnorm_fwd(xd, y, gamma.to(DEV), beta.to(DEV), mean, rstd, ws, Bn, HW, Cc, G, eps, silu)
+    dx = torch.zeros_like(xd)
+    acc = rnd(Bn * HW, Cc, seed=23).to(DEV)
+    ops.groupnorm_bwd(dy.to(DEV).view(Bn * HW, Cc), xd, gamma.to(DEV), beta.to(DEV), mean, rstd, dx, ws, Bn, HW,
+                      Cc, G, silu, accum=acc)
+    torch.cuda.synchronize()
+    check(f"gn fwd C{Cc} HW{HW} silu{silu}", y.view(Bn, HW, Cc), yr.detach().permute(0, 2, 1), 2e-3)
+    check(f"gn bwd C{Cc} HW{HW} silu{silu}", dx.view(Bn, HW, Cc).float().cpu() - acc.view(Bn, HW, Cc).float().cpu(),
+          xr.grad.permute(0, 2, 1), 4e-3)
+
+
+@pytest.mark.parametrize("Cc", [320, 768, 1280])
+@pytest.mark.parametrize("f32", [False, True])
+def test_layernorm_fwd_bwd(Cc, f32):
+    ops = _ops()
+    rows = 77
+    dt = torch.float32 if f32 else torch.float16
+    x = (rnd(rows, Cc, seed=24, dtype=torch.float32) * 2 + 0.5).to(dt)
+    gamma = 1 + 0.1 * rnd(Cc, seed=25, dtype=torch.float32)
+    beta = 0.1 * rnd(Cc, seed=26, dtype=torch.float32)
+    dy = rnd(rows, Cc, seed=27)
+    xr = x.float().requires_grad_(True)
+    yr = F.layer_norm(xr, (Cc,), gamma, beta, 1e-5)
+    yr.backward(dy.float())
+    xd = x.to(DEV)
+    y = torch.zeros(rows, Cc, dtype=torch.float16, device=DEV)
+    mean = torch.zeros(rows, dtype=torch.float32, device=DEV)
+    rstd = torch.zeros_like(mean)
+    ops.layernorm_fwd(xd, y, gamma.to(DEV), beta.to(DEV), mean, rstd, 1e-5)
+    dx = torch.zeros(rows, Cc, dtype=dt, device=DEV)
+    acc = rnd(rows, Cc, seed=28, dtype=torch.float32).to(dt).to(DEV)
+    ops.layernorm_bwd(dy.to(DEV), xd, gamma.to(DEV), mean, rstd, dx, accum=acc)
+    torch.cuda.synchronize()
+    check(f"ln fwd C{Cc} f32={f32}", y, yr.detach(), 2e-3)
+    check(f"ln bwd C{Cc} f32={f32}", dx.float().cpu() - acc.float().cpu(), xr.grad, 4e-3)
+
+
+def test_transpose_and_softmax():
+    ops = _ops()
+    Bn, rows, cols, ldo = 3, 77, 320, 80
+    x = rnd(Bn, rows, cols, seed=29).to(DEV)
+    out = torch.full((Bn, cols, ldo), 7.0, dtype=torch.float16, device=DEV)
+    ops.transpose(x, out, rows, cols, Bn, cols, rows * cols, ldo, cols * ldo)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :, :rows], x.transpose(1, 2))
+    assert out[:, :, rows:].abs().sum().item() == 0
+    s = rnd(50, 4096, scale=3.0, seed=30).to(DEV)
+    ref = torch.softmax(s.float().cpu(), -1)
+    ops.softmax_rows(s, 50, 4096)
+    torch.cuda.synchronize()
+    check("softmax rows", s, ref, 2e-3)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, H, D, scale, causal):
+    Bn, Nq, _ = q.shape
+    Nk = k.shape[1]
+    qh = q.view(Bn, Nq, H, D).transpose(1, 2)
+    kh = k.view(Bn, Nk, H, D).transpose(1, 2)
+    vh = v.view(Bn, Nk, H, D).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        mask = torch.ones(Nq, Nk, dtype=torch.bool).tril()
+        s = s.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    o = (p @ vh).transpose(1, 2).reshape(Bn, Nq, H * D)
+    lse = torch.logsumexp(s, -1)
+    return o, lse
+
+
+@pytest.mark.parametrize("D,H,Nq,Nk,causal", [
+    (40, 8, 200, 200, False), (40, 2, 300, 77, False), (64, 12, 77, 77, True), (80, 8, 128, 77, False),
+    (160, 8, 256, 256, False), (160, 2, 64, 77, False), (64, 3, 200, 200, True), (80, 2, 520, 520, False),
+])
+def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
+    ops = _ops()
+    Bn = 2
+    Cc = H * D
+    scale = D ** -0.5
+    q = rnd(Bn, Nq, Cc, seed=31)
+    k = rnd(Bn, Nk, Cc, seed=32)
+    v = rnd(Bn, Nk, Cc, seed=33)
+    do = rnd(Bn, Nq, Cc, seed=34)
+    # spike one key against one query to exercise the online-softmax rescale path
+    k[0, Nk - 3] = (q[0, min(5, Nq - 1)].float() * 3).half()
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    o_ref, lse_ref = _attn_ref(qr, kr, vr, H, D, scale, causal)
+    o_ref.backward(do.float())
+
+    qd, kd, vd, dod = (t.to(DEV).view(-1, Cc) for t in (q, k, v, do))
+    ldk = (Nk + 7) // 8 * 8
+    ldq = (Nq + 7) // 8 * 8
+    vt = torch.zeros(Bn, Cc, ldk, dtype=torch.float16, device=DEV)
+    kt = torch.zeros(Bn, Cc, ldk, dtype=torch.float16, device=DEV)
+    qt = torch.zeros(Bn, Cc, ldq, dtype=torch.float16, device=DEV)
+    dot = torch.zeros(Bn, Cc, ldq, dtype=torch.float16, device=DEV)
+    ops.transpose(vd, vt, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk)
+    ops.transpose(kd, kt, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk)
+    ops.transpose(qd, qt, Nq, Cc, Bn, Cc, Nq * Cc, ldq, Cc * ldq)
+    ops.transpose(dod, dot, Nq, Cc, Bn, Cc, Nq * Cc, ldq, Cc * ldq)
+    o = torch.zeros(Bn * Nq, Cc, dtype=torch.float16, device=DEV)
+    lse = torch.zeros(Bn, H, Nq, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(qd, kd, vt, o, lse, Bn, H, Nq, Nk, D, scale, causal, ldk)
+    torch.cuda.synchronize()
+    tag = f"D{D} H{H} Nq{Nq} Nk{Nk} c{int(causal)}"
+    check(f"attn fwd {tag}", o.view(Bn, Nq, Cc), o_ref.detach(), 3e-3)
+    check(f"attn lse {tag}", lse, lse_ref.detach(), 1e-3)
+
+    delta = torch.zeros(Bn, H, Nq, dtype=torch.float32, device=DEV)
+    ops.attn_bwd_delta(dod, o, delta, Bn, H, Nq, D)
+    dq = torch.zeros(Bn * Nq, Cc, dtype=torch.float16, device=DEV)
+    dk = torch.zeros(Bn * Nk, Cc, dtype=torch.float16, device=DEV)
+    dv = torch.zeros(Bn * Nk, Cc, dtype=torch.float16, device=DEV)
+    ops.attn_bwd_dq(qd, kd, kt, ldk, vd, dod, lse, delta, dq, Bn, H, Nq, Nk, D, scale, causal)
+    ops.attn_bwd_dkv(qd, qt, ldq, kd, vd, dod, dot, ldq, lse, delta, dk, dv, Bn, H, Nq, Nk, D, scale, causal)
+    torch.cuda.synchronize()
+    check(f"attn dq {tag}", dq.view(Bn, Nq, Cc), qr.grad, 6e-3)
+    check(f"attn dk {tag}", dk.view(Bn, Nk, Cc), kr.grad, 6e-3)
+    check(f"attn dv {tag}", dv.view(Bn, Nk, Cc), vr.grad, 6e-3)

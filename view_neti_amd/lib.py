@@ -1,0 +1,126 @@
+"""ctypes binding of libvneti_hip.so (the C ABI declared in include/vneti.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  `load()` never builds implicitly on a machine without hipcc; use
+`__graft_entry__.build()` / `python view_neti_amd/csrc/build.py` to compile.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libvneti_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vneti.h")
+
+_lib = None
+
+c_ll = C.c_longlong
+c_vp = C.c_void_p
+c_int = C.c_int
+c_f = C.c_float
+
+
+class GemmDesc(C.Structure):
+    """Mirror of `vneti_gemm_desc` (include/vneti.h)."""
+
+    _fields_ = [
+        ("A", c_vp), ("B", c_vp), ("C", c_vp),
+        ("lda", c_ll), ("ldb", c_ll), ("ldc", c_ll),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("batch", c_int),
+        ("strideA", c_ll), ("strideB", c_ll), ("strideC", c_ll),
+        ("bias", c_vp),
+        ("rowadd", c_vp), ("ld_rowadd", c_ll), ("rows_per_group", c_int),
+        ("resid", c_vp), ("ldr", c_ll),
+        ("alpha", c_f), ("act", c_int), ("out_f32", c_int),
+        ("conv_mode", c_int),
+        ("Hi", c_int), ("Wi", c_int), ("Ci", c_int), ("Ho", c_int), ("Wo", c_int),
+        ("stride", c_int), ("pad_t", c_int), ("pad_l", c_int), ("ups", c_int),
+        ("ldx", c_ll),
+        ("tile_hint", c_int),
+    ]
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/vneti.h (used by the CPU test suite)."""
+    src = open(HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vneti_[a-z0-9_]+)\s*\(", src)))
+
+
+def load():
+    """Load the library once; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"libvneti_hip.so not found at {SO_PATH}: build it with "
+            "`python view_neti_amd/csrc/build.py` (hipcc, gfx950). There is no fallback path.")
+    lib = C.CDLL(SO_PATH)
+    lib.vneti_version.restype = c_int
+    lib.vneti_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    lib.vneti_last_error.restype = c_int
+    lib.vneti_groupnorm_ws_floats.restype = c_ll
+    lib.vneti_groupnorm_ws_floats.argtypes = [c_int] * 4
+    lib.vneti_gemm_f16.argtypes = [C.POINTER(GemmDesc), c_vp]
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    lib = load()
+    buf = C.create_string_buffer(512)
+    lib.vneti_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RuntimeError(f"vneti call failed ({what}) rc={rc}: {last_error()}")
+
+
+def _conv(a):
+    """Convert python values to ctypes-friendly ones (None -> NULL pointer)."""
+    return a
+
+
+def call(name: str, *args):
+    """Call `vneti_<name>` with positional args; pointers are ints/None, scalars by python type.
+
+    Argument conversion is explicit per call-site through the typed helpers below; this generic
+    entry is used for the many small elementwise entry points whose signatures are registered
+    in SIGNATURES.
+    """
+    lib = load()
+    fn = getattr(lib, "vneti_" + name)
+    sig = SIGNATURES.get(name)
+    if sig is not None and fn.argtypes is None:
+        fn.argtypes = sig
+        fn.restype = c_int
+    rc = fn(*args)
+    check(rc, name)
+
+
+# argtypes for every int-returning entry point (kept in the same order as include/vneti.h)
+SIGNATURES = {
+    "im2col3x3_small": [c_vp, c_int, c_ll, c_ll, c_ll, c_ll, c_vp] + [c_int] * 9 + [c_vp],
+    "transpose_f16": [c_vp, c_ll, c_ll, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
+    "groupnorm_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                      c_f, c_int, c_vp],
+    "groupnorm_bwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp,
+                      c_int, c_int, c_int, c_int, c_int, c_vp],
+    "layernorm_fwd": [c_vp, c_int, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f, c_vp],
+    "layernorm_bwd": [c_vp, c_int, c_ll, c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_vp,
+                      c_ll, c_int, c_int, c_vp],
+    "attn_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_int,
+                 c_f, c_int, c_vp],
+    "attn_bwd_delta": [c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "attn_bwd_dq": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_ll,
+                    c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
+    "attn_bwd_dkv": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp,
+                     c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
+    "softmax_rows_f16": [c_vp, c_ll, c_int, c_int, c_vp],
+}

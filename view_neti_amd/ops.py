@@ -1,0 +1,134 @@
+"""Thin torch-tensor front-ends over the C ABI (include/vneti.h).
+
+torch is used only for device memory and the current HIP stream; every function below ends in
+exactly one (or, for GroupNorm, three) hand-written HIP kernel launches from libvneti_hip.so.
+All matrices are 2-D views `[rows, cols]` whose last stride is 1; the row stride may exceed
+`cols` (views into wider buffers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as _l
+
+ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2, 3
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t):
+    if t is None:
+        return 0
+    assert t.stride(-1) == 1, "last dim must be contiguous"
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alpha=1.0, act=0,
+         tile_hint=0, batch=0, strideA=0, strideB=0, strideC=0, M=None, N=None, K=None, conv=None,
+         lda=None, ldc=None):
+    """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  `conv` = dict(mode, Hi, Wi, Ci, Ho, Wo, stride,
+    pad_t, pad_l, ups, ldx) turns A into an implicit im2col view of an NHWC image."""
+    d = _l.GemmDesc()
+    d.A, d.B, d.C = _p(A), _p(B), _p(out)
+    d.ldb = _ld(B)
+    d.ldc = ldc if ldc is not None else _ld(out)
+    d.N = N if N is not None else B.shape[-2]
+    d.K = K if K is not None else B.shape[-1]
+    if conv is None:
+        d.M = M if M is not None else A.shape[-2]
+        d.lda = lda if lda is not None else _ld(A)
+        d.conv_mode = 0
+    else:
+        d.M = M
+        d.lda = 0
+        d.conv_mode = conv["mode"]
+        for k in ("Hi", "Wi", "Ci", "Ho", "Wo", "stride", "pad_t", "pad_l", "ups", "ldx"):
+            setattr(d, k, int(conv.get(k, 0)))
+    d.batch = batch
+    d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
+    d.bias = _p(bias)
+    d.rowadd = _p(rowadd)
+    d.ld_rowadd = _ld(rowadd) if rowadd is not None else 0
+    d.rows_per_group = rows_per_group
+    d.resid = _p(resid)
+    d.ldr = _ld(resid) if resid is not None else 0
+    d.alpha = alpha
+    d.act = act
+    d.out_f32 = 1 if out.dtype == torch.float32 else 0
+    d.tile_hint = tile_hint
+    rc = _l.load().vneti_gemm_f16(C.byref(d), stream())
+    _l.check(rc, "gemm_f16")
+
+
+def im2col3x3_small(x, out, Bn, Cc, Hi, Wi, Ho, Wo, stride, pad_t, pad_l, strides):
+    sb, sc, sy, sx = strides
+    _l.call("im2col3x3_small", _p(x), 1 if x.dtype == torch.float32 else 0, sb, sc, sy, sx, _p(out),
+            Bn, Cc, Hi, Wi, Ho, Wo, stride, pad_t, pad_l, stream())
+
+
+def transpose(inp, out, rows, cols, batch, ld_in, stride_in, ld_out, stride_out):
+    _l.call("transpose_f16", _p(inp), ld_in, stride_in, _p(out), ld_out, stride_out, rows, cols, batch, stream())
+
+
+def groupnorm_ws_floats(Bn, HW, Cc, G):
+    n = _l.load().vneti_groupnorm_ws_floats(Bn, HW, Cc, G)
+    if n < 0:
+        raise RuntimeError(f"groupnorm: unsupported shape {(Bn, HW, Cc, G)}")
+    return int(n)
+
+
+def groupnorm_fwd(x, y, gamma, beta, mean, rstd, ws, Bn, HW, Cc, G, eps, silu):
+    _l.call("groupnorm_fwd", _p(x), _ld(x), _p(y), _ld(y), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(ws),
+            Bn, HW, Cc, G, eps, 1 if silu else 0, stream())
+
+
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dx, ws, Bn, HW, Cc, G, silu, accum=None):
+    _l.call("groupnorm_bwd", _p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(beta), _p(mean), _p(rstd),
+            _p(dx), _ld(dx), _p(accum), _ld(accum) if accum is not None else 0, _p(ws),
+            Bn, HW, Cc, G, 1 if silu else 0, stream())
+
+
+def layernorm_fwd(x, y, gamma, beta, mean, rstd, eps):
+    rows, Cc = x.shape
+    _l.call("layernorm_fwd", _p(x), 1 if x.dtype == torch.float32 else 0, _ld(x), _p(y), _ld(y), _p(gamma),
+            _p(beta), _p(mean), _p(rstd), rows, Cc, eps, stream())
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, accum=None):
+    rows, Cc = x.shape
+    _l.call("layernorm_bwd", _p(dy), 1 if dy.dtype == torch.float32 else 0, _ld(dy), _p(x),
+            1 if x.dtype == torch.float32 else 0, _ld(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
+            1 if dx.dtype == torch.float32 else 0, _ld(dx), _p(accum),
+            _ld(accum) if accum is not None else 0, rows, Cc, stream())
+
+
+def attn_fwd(Q, K, Vt, O, lse, Bn, H, Nq, Nk, D, scale, causal, ldvt):
+    _l.call("attn_fwd", _p(Q), _ld(Q), _p(K), _ld(K), _p(Vt), ldvt, _p(O), _ld(O), _p(lse), Bn, H, Nq, Nk, D,
+            scale, 1 if causal else 0, stream())
+
+
+def attn_bwd_delta(dO, O, delta, Bn, H, Nq, D):
+    _l.call("attn_bwd_delta", _p(dO), _ld(dO), _p(O), _ld(O), _p(delta), Bn, H, Nq, D, stream())
+
+
+def attn_bwd_dq(Q, K, Kt, ldkt, V, dO, lse, delta, dQ, Bn, H, Nq, Nk, D, scale, causal):
+    _l.call("attn_bwd_dq", _p(Q), _ld(Q), _p(K), _ld(K), _p(Kt), ldkt, _p(V), _ld(V), _p(dO), _ld(dO),
+            _p(lse), _p(delta), _p(dQ), _ld(dQ), Bn, H, Nq, Nk, D, scale, 1 if causal else 0, stream())
+
+
+def attn_bwd_dkv(Q, Qt, ldqt, K, V, dO, dOt, lddot, lse, delta, dK, dV, Bn, H, Nq, Nk, D, scale, causal):
+    _l.call("attn_bwd_dkv", _p(Q), _ld(Q), _p(Qt), ldqt, _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO),
+            _p(dOt), lddot, _p(lse), _p(delta), _p(dK), _ld(dK), _p(dV), _ld(dV), Bn, H, Nq, Nk, D, scale,
+            1 if causal else 0, stream())
+
+
+def softmax_rows(x, rows, cols):
+    _l.call("softmax_rows_f16", _p(x), _ld(x), rows, cols, stream())
