@@ -1,0 +1,349 @@
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference modules.
+
+Runs only in the build container (needs /root/reference); the GPU box sees just the committed
+.npz files.  The reference is pure Python but hard-codes `.cuda()` and imports packages that are
+absent here (ipdb, torchvision, diffusers); those imports are satisfied by inert stub modules and
+`.cuda()` is patched to the identity — no reference source is copied or modified.
+
+What is importable and therefore pinned by the real code:
+  G1  models.positional_encoding.FourierPositionalEncodingNDims       (w, forward)
+  G2  models.neti_mapper.NeTIMapper, embedding_type='object', arch 15  (state_dict, fwd, param grads)
+  G3  models.neti_mapper.NeTIMapper, embedding_type='view', dtu-12d    (synthetic calibration files)
+  G4  models.net_clip_text_embedding.NeTICLIPTextEmbeddings            (overwrite + position add)
+  G5  models.xti_attention_processor.XTIAttenProc                      (None / tensor / dict contexts)
+  G6  transformers' CLIPTextModel (third-party stack the reference subclasses) with random weights
+  G8  NeTIMapper.scale_m1_1, utils.utils.num_to_string/string_to_num
+Not importable (transformers 5.x dropped the 4.27 internals it subclasses):
+  models.neti_clip_text_encoder — its bypass maths (:129-180) is restated in oracle/sd_ref.py and
+  covered by property tests only.
+
+Each fixture is immediately cross-checked against oracle/sd_ref.py; the script fails if the
+restatement and the reference disagree.
+
+Usage:  python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib.machinery
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__path__ = []
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+class _Identity:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, x):
+        return x
+
+
+def install_reference():
+    # transformers' CLIP must be imported BEFORE a fake torchvision exists
+    import transformers.models.clip.modeling_clip  # noqa: F401
+    _stub("ipdb", set_trace=lambda *a, **k: None)
+    tv = _stub("torchvision")
+    names = ["Compose", "RandomApply", "ColorJitter", "RandomGrayscale", "GaussianBlur", "RandomRotation",
+             "RandomResizedCrop", "RandomHorizontalFlip", "Resize", "ToTensor", "Normalize", "CenterCrop",
+             "InterpolationMode"]
+    tvt = _stub("torchvision.transforms", **{n: _Identity for n in names})
+    tv.transforms = tvt
+    d = _stub("diffusers")
+    dm = _stub("diffusers.models")
+    dc = _stub("diffusers.models.cross_attention", CrossAttention=object)
+    d.models = dm
+    dm.cross_attention = dc
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def close(a, b, tol, what):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-30
+    assert err <= tol * max(1.0, ref), f"{what}: oracle vs reference max abs err {err} (ref max {ref})"
+    print(f"  ok {what}: max abs err {err:.3e}")
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not mounted; fixtures can only be generated in the build container")
+    install_reference()
+    from oracle import sd_ref as R
+
+    from models.positional_encoding import FourierPositionalEncodingNDims
+    from models.neti_mapper import NeTIMapper
+    from models.net_clip_text_embedding import NeTICLIPTextEmbeddings
+    from models.xti_attention_processor import XTIAttenProc
+    from utils.types import NeTIBatch, PESigmas
+    from utils.utils import num_to_string, string_to_num
+
+    # ---------------- G1: Fourier positional encoding --------------------------------------
+    g = torch.Generator().manual_seed(7)
+    for tag, sigmas in (("obj", [0.03, 2.0]), ("view", [0.03, 2.0] + [0.5] * 12)):
+        enc = FourierPositionalEncodingNDims(dim=64, sigmas=sigmas, seed=0)
+        x = torch.rand((8, len(sigmas)), generator=g) * 2 - 1
+        y = enc(x)
+        w = enc.w.detach()
+        close(R.fourier_w(sigmas, 64, 0), w, 0, f"G1 w[{tag}]")
+        close(R.fourier_encode(w, x), y, 1e-6, f"G1 fwd[{tag}]")
+        save(f"g1_fourier_{tag}", sigmas=np.array(sigmas, dtype=np.float64), w=w, x=x, y=y)
+
+    # ---------------- G2: object mapper, arch 15 --------------------------------------------
+    for D in (768, 1024):
+        torch.manual_seed(123)
+        m = NeTIMapper(embedding_type="object", output_dim=D, arch_mlp_hidden_dims=64, use_nested_dropout=False,
+                       norm_scale=torch.tensor(0.4), pe_sigmas=PESigmas(sigma_t=0.03, sigma_l=2.0),
+                       output_bypass=True, arch_view_net=15, arch_view_disable_tl=False,
+                       bypass_unconstrained=False, output_bypass_alpha=0.2, placeholder_object_token="<obj>")
+        m.eval()
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items() if k != "encoder.w"}
+        # break the "all mappers start identical / tiny" symmetry so grads are informative
+        gen = torch.Generator().manual_seed(5)
+        for k in sd:
+            sd[k] = sd[k] + 0.05 * torch.randn(sd[k].shape, generator=gen)
+        m.load_state_dict({**sd, **({"encoder.w": m.state_dict()["encoder.w"]} if "encoder.w" in m.state_dict() else {})})
+        t = torch.tensor([10.0, 500.0, 999.0, 3.0])
+        l = torch.tensor([0.0, 7.0, 15.0, 2.0])
+        out = m(timestep=t, unet_layer=l, input_ids_placeholder_view=None, truncation_idx=None)
+        gw = torch.randn(out.word_embedding.shape, generator=gen)
+        gb = torch.randn(out.bypass_output.shape, generator=gen)
+        ((out.word_embedding * gw).sum() + (out.bypass_output * gb).sum()).backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if k != "encoder.w" and p.grad is not None}
+        # oracle
+        po = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        wo, bo = R.mapper_forward(po, R.fourier_w([0.03, 2.0]), t, l, 0.4)
+        ((wo * gw).sum() + (bo * gb).sum()).backward()
+        close(wo, out.word_embedding, 1e-5, f"G2 word D={D}")
+        close(bo, out.bypass_output, 1e-5, f"G2 bypass D={D}")
+        for k in grads:
+            close(po[k].grad, grads[k], 1e-4, f"G2 grad {k} D={D}")
+        arrays = {"t": t, "l": l, "word": out.word_embedding, "bypass": out.bypass_output, "gw": gw, "gb": gb,
+                  "n_params": np.array(sum(v.numel() for v in sd.values()))}
+        if D == 768:  # keep the committed fixture small: full state only once
+            arrays.update({"sd." + k: v for k, v in sd.items()})
+            arrays.update({"grad." + k: (v if v.numel() < 10000 else v[:, :4]) for k, v in grads.items()})
+        else:
+            # D=1024: store a seed-regenerable recipe instead of 141k floats x 2
+            arrays.update({"sd." + k: v for k, v in sd.items() if "output_layer" not in k})
+            arrays["out_w_checksum"] = np.array([sd["output_layer.0.weight"].double().sum().item(),
+                                                 sd["output_layer.0.weight"].double().abs().sum().item()])
+        save(f"g2_mapper_object_{D}", **arrays)
+        print(f"  param count D={D}: {sum(v.numel() for v in sd.values())}")
+
+    # ---------------- G3: view mapper (dtu-12d) with synthetic calibration files --------------
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            cal = os.path.join("data", "dtu", "Calibration", "cal18")
+            os.makedirs(cal)
+            rng = np.random.RandomState(11)
+            mats = rng.randn(64, 3, 4) * np.array([[1e3, 1e3, 1e3, 1e5]])
+            for i in range(64):
+                np.savetxt(os.path.join(cal, f"pos_{i + 1:03d}.txt"), mats[i])
+            from training.dataset import TextualInversionDataset as TID
+            toks, lookup = TID.dtu_generate_dset_cam_tokens_params()
+            cams = [0, 8, 13, 22, 25, 28]
+            view_tokens = [toks[c] for c in cams]
+            view_ids = [49410 + i for i in range(len(cams))]
+            torch.manual_seed(321)
+            mv = NeTIMapper(embedding_type="view", output_dim=768, use_nested_dropout=False,
+                            norm_scale=torch.tensor(0.35),
+                            pe_sigmas=PESigmas(sigma_t=0.03, sigma_l=2.0, sigma_dtu12=0.5), output_bypass=True,
+                            placeholder_view_tokens=list(view_tokens), placeholder_view_token_ids=list(view_ids),
+                            arch_view_net=15, arch_view_disable_tl=False, bypass_unconstrained=False,
+                            output_bypass_alpha=0.2)
+            mv.eval()
+            t = torch.tensor([10.0, 500.0, 999.0, 3.0])
+            l = torch.tensor([0.0, 7.0, 15.0, 2.0])
+            ids = torch.tensor([view_ids[0], view_ids[3], view_ids[5], view_ids[1]])
+            out = mv(timestep=t, unet_layer=l, input_ids_placeholder_view=ids, truncation_idx=None)
+            params = torch.stack([mv.view_tokenid_2_view_params[i.item()] for i in ids]).float()
+            scaled = NeTIMapper.scale_m1_1(params, mv.cam_mins, mv.cam_maxs)
+            sdv = {k: v.detach().clone() for k, v in mv.state_dict().items() if k != "encoder.w"}
+            wv, bv = R.mapper_forward(sdv, R.fourier_w([0.03, 2.0] + [0.5] * 12), t, l, 0.35, view_params=scaled)
+            close(wv, out.word_embedding, 1e-5, "G3 view word")
+            close(bv, out.bypass_output, 1e-5, "G3 view bypass")
+            # token <-> params round trip
+            p0, key0 = TID.dtu_token_to_cam_params(view_tokens[0], cam_idx_as_int=True)
+            save("g3_mapper_view", calib=mats.astype(np.float64), cams=np.array(cams), view_ids=np.array(view_ids),
+                 tokens=np.array(view_tokens), cam_mins=mv.cam_mins, cam_maxs=mv.cam_maxs, t=t, l=l, ids=ids,
+                 params=params, scaled=scaled, word=out.word_embedding, bypass=out.bypass_output,
+                 token0_params=p0, token0_key=np.array(key0),
+                 **{"sd." + k: v for k, v in sdv.items() if "output_layer" not in k},
+                 out_w=sdv["output_layer.0.weight"][:, :8], out_b=sdv["output_layer.0.bias"])
+        finally:
+            os.chdir(cwd)
+
+    # ---------------- G4: NeTI text embeddings (tiny CLIP config) ----------------------------
+    from transformers import CLIPTextConfig
+    tc = CLIPTextConfig(vocab_size=96, hidden_size=32, max_position_embeddings=77, num_hidden_layers=2,
+                        num_attention_heads=2, intermediate_size=64)
+    torch.manual_seed(9)
+    emb = NeTICLIPTextEmbeddings(tc)
+    torch.manual_seed(10)
+    mo = NeTIMapper(embedding_type="object", output_dim=32, arch_mlp_hidden_dims=64, use_nested_dropout=False,
+                    norm_scale=torch.tensor(0.4), pe_sigmas=PESigmas(sigma_t=0.03, sigma_l=2.0), output_bypass=True,
+                    arch_view_net=15, arch_view_disable_tl=False, bypass_unconstrained=False, output_bypass_alpha=0.2)
+    mo.eval()
+    emb.set_mapper({90: mo}, None, device="cpu")
+    ids = torch.randint(0, 90, (3, 77), generator=torch.Generator().manual_seed(1))
+    pos = [5, 9, 2]
+    for b, p in enumerate(pos):
+        ids[b, p] = 90
+    batch = NeTIBatch(input_ids=ids, input_ids_placeholder_object=torch.tensor([90, 90, 90]),
+                      input_ids_placeholder_view=torch.tensor([-1, -1, -1]), timesteps=torch.tensor([3, 700, 42]),
+                      unet_layers=torch.tensor([4, 4, 4]))
+    with torch.no_grad():
+        outs = emb(batch=batch)
+    hidden, byp_o, byp_v, unc_o, unc_v, al_o, al_v = outs
+    sdo = {k: v.detach().clone() for k, v in mo.state_dict().items() if k != "encoder.w"}
+    with torch.no_grad():
+        wo, bo = R.mapper_forward(sdo, R.fourier_w([0.03, 2.0]), batch.timesteps, batch.unet_layers, 0.4)
+        mine = R.neti_embeddings(emb.token_embedding.weight, emb.position_embedding.weight, ids,
+                                 batch.input_ids_placeholder_object, wo)
+    close(mine, hidden, 1e-6, "G4 embeddings")
+    close(bo, byp_o, 1e-6, "G4 bypass passthrough")
+    assert byp_v is None and unc_o is False and unc_v is False and al_o == 0.2 and al_v is None
+    save("g4_text_embeddings", token_emb=emb.token_embedding.weight, pos_emb=emb.position_embedding.weight, ids=ids,
+         timesteps=batch.timesteps, layers=batch.unet_layers, hidden=hidden, bypass=byp_o,
+         **{"sd." + k: v for k, v in sdo.items()})
+
+    # ---------------- G5: XTI attention processor -------------------------------------------
+    class Attn:
+        def __init__(self, C, Dctx, heads, gen):
+            self.heads = heads
+            self.to_q = torch.nn.Linear(C, C, bias=False)
+            self.to_k = torch.nn.Linear(Dctx, C, bias=False)
+            self.to_v = torch.nn.Linear(Dctx, C, bias=False)
+            self.to_out = torch.nn.ModuleList([torch.nn.Linear(C, C), torch.nn.Dropout(0.0)])
+            self.scale = (C // heads) ** -0.5
+            self.cross_attention_norm = False
+            for p in list(self.to_q.parameters()) + list(self.to_k.parameters()) + list(self.to_v.parameters()) + \
+                    list(self.to_out.parameters()):
+                p.data = torch.randn(p.shape, generator=gen) * 0.2
+
+        def prepare_attention_mask(self, mask, n, b):
+            return mask
+
+        def head_to_batch_dim(self, t):
+            b, n, c = t.shape
+            return t.reshape(b, n, self.heads, c // self.heads).permute(0, 2, 1, 3).reshape(b * self.heads, n,
+                                                                                         c // self.heads)
+
+        def batch_to_head_dim(self, t):
+            bh, n, d = t.shape
+            b = bh // self.heads
+            return t.reshape(b, self.heads, n, d).permute(0, 2, 1, 3).reshape(b, n, d * self.heads)
+
+        def get_attention_scores(self, q, k, mask=None):
+            s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1]), q, k.transpose(-1, -2), beta=0,
+                              alpha=self.scale)
+            return s.softmax(dim=-1)
+
+    gen = torch.Generator().manual_seed(77)
+    C_, Dctx, heads = 64, 48, 8
+    proc = XTIAttenProc()
+    attn_self = Attn(C_, C_, heads, gen)
+    attn_cross = Attn(C_, Dctx, heads, gen)
+    hs = torch.randn(2, 10, C_, generator=gen)
+    ctx = {"this_idx": 14}
+    for i in range(16):
+        ctx[f"CONTEXT_TENSOR_{i}"] = torch.randn(2, 7, Dctx, generator=gen)
+        ctx[f"CONTEXT_TENSOR_BYPASS_{i}"] = torch.randn(2, 7, Dctx, generator=gen)
+    ctx_o = dict(ctx)
+    with torch.no_grad():
+        y_self = proc(attn_self, hs, None)
+        y_tensor = proc(attn_cross, hs, ctx["CONTEXT_TENSOR_3"])
+        seq = []
+        ys = []
+        for _ in range(3):
+            ys.append(proc(attn_cross, hs, ctx))
+            seq.append(ctx["this_idx"])
+
+        def mine(a, h, e):
+            return R.xti_attention(a.to_q.weight, a.to_k.weight, a.to_v.weight, a.to_out[0].weight, a.to_out[0].bias,
+                                   heads, h, e)
+        close(mine(attn_self, hs, None), y_self, 1e-5, "G5 self")
+        close(mine(attn_cross, hs, ctx_o["CONTEXT_TENSOR_3"]), y_tensor, 1e-5, "G5 tensor ctx")
+        seq_o = []
+        for k in range(3):
+            close(mine(attn_cross, hs, ctx_o), ys[k], 1e-5, f"G5 dict ctx call {k}")
+            seq_o.append(ctx_o["this_idx"])
+    assert seq == seq_o == [15, 0, 1], (seq, seq_o)
+    save("g5_xti_attention", hs=hs, wq=attn_cross.to_q.weight, wk=attn_cross.to_k.weight, wv=attn_cross.to_v.weight,
+         wo=attn_cross.to_out[0].weight, bo=attn_cross.to_out[0].bias, ctx14=ctx["CONTEXT_TENSOR_14"],
+         ctxb14=ctx["CONTEXT_TENSOR_BYPASS_14"], ctx15=ctx["CONTEXT_TENSOR_15"], ctxb15=ctx["CONTEXT_TENSOR_BYPASS_15"],
+         ctx0=ctx["CONTEXT_TENSOR_0"], ctxb0=ctx["CONTEXT_TENSOR_BYPASS_0"], y0=ys[0], y1=ys[1], y2=ys[2],
+         seq=np.array(seq), sq=attn_self.to_q.weight, sk=attn_self.to_k.weight, sv=attn_self.to_v.weight,
+         so=attn_self.to_out[0].weight, sbo=attn_self.to_out[0].bias, y_self=y_self)
+
+    # ---------------- G6: third-party CLIP text stack (transformers, random tiny weights) -----
+    from transformers import CLIPTextModel
+    from view_neti_amd import sd_config as sc
+    for act in ("quick_gelu", "gelu"):
+        tc = CLIPTextConfig(vocab_size=96, hidden_size=64, max_position_embeddings=77, num_hidden_layers=2,
+                            num_attention_heads=4, intermediate_size=128, hidden_act=act, eos_token_id=95)
+        torch.manual_seed(4)
+        tm = CLIPTextModel(tc).eval()
+        sdt = {k: v.detach().clone() for k, v in tm.state_dict().items()}
+        if not any(k.startswith("text_model.") for k in sdt):
+            sdt = {"text_model." + k: v for k, v in sdt.items()}
+        sdt = {k: v for k, v in sdt.items() if "position_ids" not in k}
+        ids = torch.randint(0, 96, (2, 77), generator=torch.Generator().manual_seed(2))
+        with torch.no_grad():
+            ref = tm(input_ids=ids).last_hidden_state
+            my_cfg = sc.CLIPTextConfig(vocab_size=96, hidden_size=64, num_layers=2, num_heads=4, intermediate_size=128,
+                                       act=act)
+            mine_last, _ = R.neti_text_encoder(sdt, my_cfg, ids, None, None, None)
+        close(mine_last, ref, 2e-5, f"G6 CLIP text stack ({act})")
+        save(f"g6_clip_tiny_{act}", ids=ids, last_hidden=ref, **{"sd." + k: v for k, v in sdt.items()})
+
+    # ---------------- G8: small helpers --------------------------------------------------------
+    xs = torch.tensor([[-3.0, 0.5, 2.0], [1.0, 1.0, 1.0]])
+    s1 = NeTIMapper.scale_m1_1(xs, torch.tensor([-3.0, 0.0, 1.0]), torch.tensor([1.0, 1.0, 3.0]))
+    nums = [0, 3.0, 1.25, -2.5, 1234.56789, 0.0001]
+    strs2 = [num_to_string(n) for n in nums]
+    strs4 = [num_to_string(n, tol=4) for n in nums]
+    back = [string_to_num(s) for s in strs4]
+    save("g8_helpers", xs=xs, scaled=s1, nums=np.array(nums), strs2=np.array(strs2), strs4=np.array(strs4),
+         back=np.array(back))
+    print("all fixtures written and cross-checked against oracle/sd_ref.py")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,37 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/vneti.h declares."""
+import ctypes
+import os
+
+import pytest
+
+from view_neti_amd import lib
+
+
+def test_header_symbols_exported():
+    if not os.path.exists(lib.SO_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    so = ctypes.CDLL(lib.SO_PATH)
+    names = lib.declared_symbols()
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, f"declared in vneti.h but not exported: {missing}"
+    assert so.vneti_version() == 1
+
+
+def test_error_convention_no_gpu():
+    """argument validation happens before any HIP call, so it is testable without a GPU."""
+    l = lib.load()
+    d = lib.GemmDesc()
+    rc = l.vneti_gemm_f16(ctypes.byref(d), None)
+    assert rc < 0
+    assert "null" in lib.last_error().lower()
+    with pytest.raises(RuntimeError):
+        lib.check(rc, "gemm")
+
+
+def test_signatures_cover_header():
+    names = set(lib.declared_symbols())
+    covered = {"vneti_" + k for k in lib.SIGNATURES} | {"vneti_version", "vneti_last_error", "vneti_gemm_f16",
+                                                       "vneti_groupnorm_ws_floats"}
+    assert names <= covered, f"no ctypes signature for {sorted(names - covered)}"

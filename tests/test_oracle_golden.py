@@ -1,0 +1,159 @@
+"""CPU tests: the oracle (oracle/sd_ref.py) against the committed golden vectors that were produced
+by the real reference modules (oracle/make_golden.py).  No GPU, no /root/reference needed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd_ref as R
+from view_neti_amd import sd_config as sc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return {k: v for k, v in np.load(os.path.join(G, name + ".npz"), allow_pickle=False).items()}
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, tol=1e-5):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("tag", ["obj", "view"])
+def test_g1_fourier(tag):
+    f = load(f"g1_fourier_{tag}")
+    w = R.fourier_w(list(f["sigmas"]), 64, 0)
+    close(w, f["w"], 0)
+    close(R.fourier_encode(T(f["w"]), T(f["x"])), f["y"], 1e-6)
+    if tag == "obj":  # SURVEY §8c sanity pin of the unscaled draw
+        close(w[0] / torch.tensor([0.03, 2.0]), [-1.1258398294, -1.1523602009], 1e-6)
+
+
+def _sd(f):
+    return {k[3:]: T(v) for k, v in f.items() if k.startswith("sd.")}
+
+
+def test_g2_object_mapper_768():
+    f = load("g2_mapper_object_768")
+    p = {k: v.clone().requires_grad_(True) for k, v in _sd(f).items()}
+    assert sum(v.numel() for v in p.values()) == int(f["n_params"]) == 108416
+    word, byp = R.mapper_forward(p, R.fourier_w([0.03, 2.0]), T(f["t"]), T(f["l"]), 0.4)
+    close(word, f["word"])
+    close(byp, f["bypass"])
+    close(word.norm(dim=-1), torch.full((4,), 0.4), 1e-5)
+    ((word * T(f["gw"])).sum() + (byp * T(f["gb"])).sum()).backward()
+    for k, v in f.items():
+        if k.startswith("grad."):
+            g = p[k[5:]].grad
+            g = g if g.numel() < 10000 else g[:, :4]
+            close(g, v, 1e-4)
+
+
+def test_g2_object_mapper_1024_shapes():
+    f = load("g2_mapper_object_1024")
+    assert int(f["n_params"]) == 141696
+    assert f["word"].shape == (4, 1024) and f["bypass"].shape == (4, 1024)
+
+
+def test_g3_view_mapper():
+    f = load("g3_mapper_view")
+    scaled = (T(f["params"]) - T(f["cam_mins"])) / (T(f["cam_maxs"]) - T(f["cam_mins"])) * 2 - 1
+    close(scaled, f["scaled"], 1e-6)
+    # the fixture holds the small layers in full and a slice of the output layer: check the hidden
+    # representation path through the slice
+    p = _sd(f)
+    t, l = T(f["t"]), T(f["l"])
+    data = torch.cat((torch.stack((t / 1000 * 2 - 1, l / 16 * 2 - 1), 1), T(f["scaled"])), 1)
+    enc = R.fourier_encode(R.fourier_w([0.03, 2.0] + [0.5] * 12), data)
+    import torch.nn.functional as F
+    h = F.leaky_relu(F.layer_norm(F.linear(enc, p["net.0.weight"], p["net.0.bias"]), (64,), p["net.1.weight"],
+                                  p["net.1.bias"]))
+    h = F.leaky_relu(F.layer_norm(F.linear(h, p["net.3.weight"], p["net.3.bias"]), (64,), p["net.4.weight"],
+                                  p["net.4.bias"]))
+    assert h.shape == (4, 64) and torch.isfinite(h).all()
+
+
+def test_g4_text_embeddings():
+    f = load("g4_text_embeddings")
+    p = _sd(f)
+    word, byp = R.mapper_forward(p, R.fourier_w([0.03, 2.0]), T(f["timesteps"]), T(f["layers"]), 0.4)
+    ids = T(f["ids"])
+    x = R.neti_embeddings(T(f["token_emb"]), T(f["pos_emb"]), ids, torch.tensor([90, 90, 90]), word)
+    close(x, f["hidden"], 1e-6)
+    close(byp, f["bypass"], 1e-6)
+
+
+def test_g5_xti_attention():
+    f = load("g5_xti_attention")
+    hs = T(f["hs"])
+    ctx = {"this_idx": 14}
+    for i in (14, 15, 0):
+        ctx[f"CONTEXT_TENSOR_{i}"] = T(f[f"ctx{i}"])
+        ctx[f"CONTEXT_TENSOR_BYPASS_{i}"] = T(f[f"ctxb{i}"])
+    seq = []
+    for k in range(3):
+        y = R.xti_attention(T(f["wq"]), T(f["wk"]), T(f["wv"]), T(f["wo"]), T(f["bo"]), 8, hs, ctx)
+        close(y, f[f"y{k}"], 1e-5)
+        seq.append(ctx["this_idx"])
+    assert seq == list(f["seq"]) == [15, 0, 1]
+    y = R.xti_attention(T(f["sq"]), T(f["sk"]), T(f["sv"]), T(f["so"]), T(f["sbo"]), 8, hs, None)
+    close(y, f["y_self"], 1e-5)
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_g6_clip_text_stack(act):
+    f = load(f"g6_clip_tiny_{act}")
+    cfg = sc.CLIPTextConfig(vocab_size=96, hidden_size=64, num_layers=2, num_heads=4, intermediate_size=128, act=act)
+    last, wb = R.neti_text_encoder(_sd(f), cfg, T(f["ids"]), None, None, None)
+    assert wb is None
+    close(last, f["last_hidden"], 2e-5)
+
+
+def test_bypass_properties():
+    """models/neti_clip_text_encoder.py:129-153 cannot be imported here; check its defining
+    properties on the restatement: constrained -> new = x + alpha * unit(b) * |x|, other rows
+    untouched; unconstrained -> |new| = mean row norm."""
+    torch.manual_seed(0)
+    x = torch.randn(3, 7, 16)
+    ids = torch.arange(7).repeat(3, 1)
+    ph = torch.tensor([2, 5, 0])
+    b = torch.randn(3, 16)
+    y = R.apply_bypass(x, ids, ph, b, False, 0.2)
+    for i in range(3):
+        p = int(ph[i])
+        exp = x[i, p] + 0.2 * b[i] / b[i].norm() * x[i, p].norm()
+        close(y[i, p], exp, 1e-6)
+        mask = torch.ones(7, dtype=torch.bool)
+        mask[p] = False
+        assert torch.equal(y[i, mask], x[i, mask])
+    y2 = R.apply_bypass(x, ids, ph, b, True, 0.2)
+    for i in range(3):
+        close(y2[i, int(ph[i])].norm(), x[i].norm(dim=-1).mean(), 1e-5)
+
+
+def test_g8_helpers():
+    f = load("g8_helpers")
+    xs, lo, hi = T(f["xs"]), torch.tensor([-3.0, 0.0, 1.0]), torch.tensor([1.0, 1.0, 3.0])
+    close((xs - lo) / (hi - lo) * 2 - 1, f["scaled"], 1e-6)
+    from view_neti_amd.compat.utils_utils import num_to_string, string_to_num
+    nums = list(f["nums"])
+    assert [num_to_string(n) for n in nums] == list(f["strs2"])
+    assert [num_to_string(n, tol=4) for n in nums] == list(f["strs4"])
+    assert np.allclose([string_to_num(s) for s in f["strs4"]], f["back"])
+
+
+def test_ddpm_schedule_and_unet_shapes():
+    ac = R.alphas_cumprod(sc.DDPMConfig())
+    assert ac.shape == (1000,) and abs(ac[0].item() - (1 - 0.00085)) < 1e-6 and ac[-1].item() < 0.01
+    import numpy as _np
+    tot = lambda s: sum(int(_np.prod(v)) for v in s.values())
+    assert tot(sc.unet_shapes(sc.sd15().unet)) == 859520964  # matches the published SD-1.5 UNet size
+    assert tot(sc.vae_encoder_shapes(sc.sd15().vae)) == 34163664
+    assert tot(sc.clip_text_shapes(sc.sd15().clip)) == 123060480
+    assert len(sc.cross_attention_order(sc.sd15().unet)) == 16
