@@ -149,6 +149,52 @@ int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, long long l
 /* row softmax in place on f16 [rows][ld] (unfused attention of the VAE mid-block, d=512) */
 int vneti_softmax_rows_f16(void* x, long long ld, int rows, int cols, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Element-wise / small kernels
+ * ------------------------------------------------------------------------------------------ */
+/* out = a + b on f16 [rows][cols] views (gradient accumulation where two paths meet) */
+int vneti_add_f16(const void* a, long long lda, const void* b, long long ldb, void* out,
+                  long long ldo, int rows, int cols, void* stream);
+/* diffusers GEGLU (FeedForward.net.0): p = [h | g], out = h * gelu(g); and its backward */
+int vneti_geglu_fwd(const void* p, long long ldp, void* out, long long ldo, int rows, int C4,
+                    void* stream);
+int vneti_geglu_bwd(const void* dy, long long lddy, const void* p, long long ldp, void* dp,
+                    long long lddp, int rows, int C4, void* stream);
+/* y = act(x) / dx = dy*act'(x), contiguous f16, act: 1 SiLU, 2 quick-GELU, 3 GELU (CLIP MLP) */
+int vneti_act_fwd_f16(const void* x, void* y, long long n, int act, void* stream);
+int vneti_act_bwd_f16(const void* dy, const void* x, void* dx, long long n, int act, void* stream);
+/* diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): t int64 [B] -> f16 [B][dim] */
+int vneti_timestep_embedding(const void* t, void* out, int Bn, int dim, void* stream);
+/* backward of nearest-2x upsample: out[b][y][x] = sum of the 2x2 block of in (NHWC f16) */
+int vneti_sum2x2_f16(const void* in, long long ldi, void* out, long long ldo, int Bn, int H, int W,
+                     int C, void* stream);
+/* device RNG (counter hash + Box-Muller) so the step is graph-capturable:
+ * state = uint32[2] {seed, step counter}.  Replaces torch.randn_like / torch.randint of
+ * training/coach.py:172-178 (stream differs from torch's Philox: documented deviation). */
+int vneti_rng_fill_normal(void* out_f32, long long n, const void* state, unsigned stream_id,
+                          void* stream);
+int vneti_rng_fill_randint(void* out_i64, int n, int high, const void* state, unsigned stream_id,
+                           void* stream);
+int vneti_rng_advance(void* state, void* stream);
+/* latent_dist.sample() * scaling_factor, DDPMScheduler.add_noise and the loss target
+ * (training/coach.py:167-183,201-205) in one kernel.  moments: NHWC f16 [B][HW][ldm] (mean|logvar);
+ * eps, noise, outputs: NCHW f32 [B][Lc][HW]. */
+int vneti_sample_add_noise(const void* moments, long long ldm, const float* eps,
+                           const float* noise, const void* timesteps_i64,
+                           const float* alphas_cumprod, float scaling, int v_prediction,
+                           float* latents, float* noisy, float* target, int Bn, int Lc, int HW,
+                           void* stream);
+/* F.mse_loss(pred.float(), target.float()) partial sum (+= into loss_sum[0]) and the scaled
+ * gradient seed dpred = 2 (pred - target) / N * loss_scale[0]  (training/coach.py:211-214) */
+int vneti_mse_loss_grad(const void* pred, long long ldp, const float* target, void* dpred,
+                        long long lddp, float* loss_sum, const float* loss_scale, int Bn, int Lc,
+                        int HW, void* stream);
+/* torch.optim.AdamW over one flat f32 bucket with torch.cuda.amp.GradScaler semantics
+ * (training/coach.py:214-218,750-756).  hyper = {lr, beta1, beta2, eps, weight_decay, grad_div};
+ * scaler = {loss_scale, growth_tracker, found_inf}; step = int32 optimizer step count. */
+int vneti_adamw_flat(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
+                     float* scaler, int* step, int growth_interval, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,4 +123,18 @@ SIGNATURES = {
     "attn_bwd_dkv": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp,
                      c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
     "softmax_rows_f16": [c_vp, c_ll, c_int, c_int, c_vp],
+    "add_f16": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_vp],
+    "geglu_fwd": [c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_vp],
+    "geglu_bwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_vp],
+    "act_fwd_f16": [c_vp, c_vp, c_ll, c_int, c_vp],
+    "act_bwd_f16": [c_vp, c_vp, c_vp, c_ll, c_int, c_vp],
+    "timestep_embedding": [c_vp, c_vp, c_int, c_int, c_vp],
+    "sum2x2_f16": [c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp],
+    "rng_fill_normal": [c_vp, c_ll, c_vp, C.c_uint, c_vp],
+    "rng_fill_randint": [c_vp, c_int, c_int, c_vp, C.c_uint, c_vp],
+    "rng_advance": [c_vp, c_vp],
+    "sample_add_noise": [c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int,
+                         c_vp],
+    "mse_loss_grad": [c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    "adamw_flat": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_vp],
 }

@@ -132,3 +132,62 @@ def attn_bwd_dkv(Q, Qt, ldqt, K, V, dO, dOt, lddot, lse, delta, dK, dV, Bn, H, N
 
 def softmax_rows(x, rows, cols):
     _l.call("softmax_rows_f16", _p(x), _ld(x), rows, cols, stream())
+
+
+def add(a, b, out):
+    rows, cols = out.shape
+    _l.call("add_f16", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), rows, cols, stream())
+
+
+def geglu_fwd(p, out):
+    rows, c4 = out.shape
+    _l.call("geglu_fwd", _p(p), _ld(p), _p(out), _ld(out), rows, c4, stream())
+
+
+def geglu_bwd(dy, p, dp):
+    rows, c4 = dy.shape
+    _l.call("geglu_bwd", _p(dy), _ld(dy), _p(p), _ld(p), _p(dp), _ld(dp), rows, c4, stream())
+
+
+def act_fwd(x, y, act):
+    _l.call("act_fwd_f16", _p(x), _p(y), x.numel(), act, stream())
+
+
+def act_bwd(dy, x, dx, act):
+    _l.call("act_bwd_f16", _p(dy), _p(x), _p(dx), x.numel(), act, stream())
+
+
+def timestep_embedding(t, out):
+    Bn, dim = out.shape
+    _l.call("timestep_embedding", _p(t), _p(out), Bn, dim, stream())
+
+
+def sum2x2(inp, out, Bn, H, W, Cc):
+    _l.call("sum2x2_f16", _p(inp), _ld(inp), _p(out), _ld(out), Bn, H, W, Cc, stream())
+
+
+def rng_fill_normal(out, state, stream_id):
+    _l.call("rng_fill_normal", _p(out), out.numel(), _p(state), stream_id, stream())
+
+
+def rng_fill_randint(out, high, state, stream_id):
+    _l.call("rng_fill_randint", _p(out), out.numel(), high, _p(state), stream_id, stream())
+
+
+def rng_advance(state):
+    _l.call("rng_advance", _p(state), stream())
+
+
+def sample_add_noise(moments, eps, noise, t, ac, scaling, vpred, latents, noisy, target, Bn, Lc, HW):
+    _l.call("sample_add_noise", _p(moments), _ld(moments), _p(eps), _p(noise), _p(t), _p(ac), scaling,
+            1 if vpred else 0, _p(latents), _p(noisy), _p(target), Bn, Lc, HW, stream())
+
+
+def mse_loss_grad(pred, target, dpred, loss_sum, loss_scale, Bn, Lc, HW):
+    _l.call("mse_loss_grad", _p(pred), _ld(pred), _p(target), _p(dpred), _ld(dpred), _p(loss_sum), _p(loss_scale),
+            Bn, Lc, HW, stream())
+
+
+def adamw_flat(p, g, m, v, hyper, scaler, step, growth_interval=2000):
+    _l.call("adamw_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(scaler), _p(step), growth_interval,
+            stream())
