@@ -1,0 +1,219 @@
+"""Shared machinery of the static HIP launch schedules (UNet, VAE encoder, text encoder).
+
+A schedule is built once for fixed shapes: `fwd` / `bwd` are plain lists of bound kernel launches
+(functools.partial over view_neti_amd.ops), replayed in order on the current stream — which makes
+the whole train step capturable in one hipGraph.  Gradient accumulation where two paths meet is
+resolved while the backward list is built (in execution order): the first contribution writes,
+later ones accumulate in place through the kernels' fused residual/accumulate operands.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Dict, List
+
+import torch
+
+from .. import ops, packing
+
+
+class T:
+    """Activation handle: forward view `v`, gradient view `g`, and whether `g` already holds a
+    contribution (tracked in backward *execution* order while the schedule is built)."""
+
+    __slots__ = ("v", "g", "gw", "rows", "cols", "children", "need_grad")
+
+    def __init__(self, v, g=None, need_grad=True):
+        self.v = v
+        self.g = g
+        self.gw = False
+        self.rows, self.cols = v.shape
+        self.children: List["T"] = []
+        self.need_grad = need_grad
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Schedule:
+    def __init__(self, batch: int, groups: int, eps: float, device: str = "cuda", need_backward: bool = True):
+        self.B = batch
+        self.groups = groups
+        self.eps = eps
+        self.dev = device
+        self.need_backward = need_backward
+        self.fwd: List = []
+        self.bwd: List = []
+        self.tape: List = []
+        self.bytes = 0
+        self._scratch: Dict[str, torch.Tensor] = {}
+        self.temb_off: Dict[str, tuple] = {}
+        self.temb_all = None
+        # vneti_groupnorm_ws_floats upper bound: <=256 slabs x 2G partials + 2*B*G finals
+        self.gn_ws = self._buf((batch * 256 * 2 * groups + 2 * batch * groups,), torch.float32)
+
+    # ------------------------------------------------------------------ memory helpers
+    def _buf(self, shape, dtype=torch.float16, zero=False):
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+    def _tmp(self, name, rows, cols, dtype=torch.float16):
+        """reusable scratch for backward temporaries (single stream => sequential lifetimes)."""
+        key = f"{name}:{dtype}"
+        n = rows * cols
+        cur = self._scratch.get(key)
+        if cur is None or cur.numel() < n:
+            self._scratch[key] = self._buf((n,), dtype)
+            cur = self._scratch[key]
+        return cur[:n].view(rows, cols)
+
+    def _w16(self, t):
+        w = t.to(device=self.dev, dtype=torch.float16).contiguous()
+        self.bytes += w.numel() * 2
+        return w
+
+    def _w32(self, t):
+        w = t.to(device=self.dev, dtype=torch.float32).contiguous()
+        self.bytes += w.numel() * 4
+        return w
+
+    # ------------------------------------------------------------------ gradient bookkeeping
+    def _grad(self, t: T):
+        if t.g is None:
+            t.g = self._buf((t.rows, t.cols))
+        return t.g
+
+    def _contrib(self, t: T, fn, extra=None):
+        """fn(out, accum) must launch a kernel computing out = result (+ accum)."""
+        g = self._grad(t)
+        if t.gw:
+            if extra is not None:
+                self.bwd.append(partial(ops.add, g, extra, g))
+            self.bwd.append(partial(fn, g, g))
+        else:
+            self.bwd.append(partial(fn, g, extra))
+            t.gw = True
+            for c in t.children:
+                c.gw = True
+
+    # ------------------------------------------------------------------ layer builders
+    def _gn(self, x: T, name, w, eps, silu):
+        Cc = x.cols
+        hw = x.rows // self.B
+        rec = dict(kind="gn", x=x, gamma=self._w32(w[name + ".weight"]), beta=self._w32(w[name + ".bias"]),
+                   mean=self._buf((self.B * self.groups,), torch.float32),
+                   rstd=self._buf((self.B * self.groups,), torch.float32), silu=silu, hw=hw)
+        y = self._buf((x.rows, Cc))
+        self.fwd.append(partial(ops.groupnorm_fwd, x.v, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"],
+                                self.gn_ws, self.B, hw, Cc, self.groups, eps, silu))
+        return y, rec
+
+    def _gn_bwd_fn(self, rec, dy):
+        x = rec["x"]
+        return lambda out, accum: ops.groupnorm_bwd(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
+                                                    self.gn_ws, self.B, rec["hw"], x.cols, self.groups,
+                                                    rec["silu"], accum=accum)
+
+    def _conv_desc(self, Hi, Wi, Ci, Ho, Wo, stride, pad, ups, ldx, mode=1):
+        return dict(mode=mode, Hi=Hi, Wi=Wi, Ci=Ci, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad, pad_l=pad, ups=ups,
+                    ldx=ldx)
+
+    def _resnet(self, x: T, cin, cout, name, w, out_view, h, wd, need_dx=True):
+        """ResnetBlock2D: GN+SiLU -> conv1 (+ time-embedding row add) -> GN+SiLU -> conv2 + shortcut."""
+        M = x.rows
+        n1, gn1 = self._gn(x, name + "norm1", w, self.eps, True)
+        w1 = self._w16(packing.conv3x3_fwd(w[name + "conv1.weight"]))
+        b1 = self._w32(w[name + "conv1.bias"])
+        radd = None
+        if name in self.temb_off:
+            off, n = self.temb_off[name]
+            radd = self.temb_all[:, off:off + n]
+        h1 = T(self._buf((M, cout)))
+        self.fwd.append(partial(ops.gemm, n1, w1, h1.v, bias=b1, rowadd=radd, rows_per_group=h * wd, M=M,
+                                conv=self._conv_desc(h, wd, cin, h, wd, 1, 1, 0, cin)))
+        n2, gn2 = self._gn(h1, name + "norm2", w, self.eps, True)
+        w2 = self._w16(packing.conv3x3_fwd(w[name + "conv2.weight"]))
+        b2 = self._w32(w[name + "conv2.bias"])
+        out = T(out_view if out_view is not None else self._buf((M, cout)))
+        wsc = None
+        if cin != cout:
+            wsc = self._w16(w[name + "conv_shortcut.weight"].reshape(cout, cin))
+            bsc = self._w32(w[name + "conv_shortcut.bias"])
+            sc_buf = self._buf((M, cout))
+            self.fwd.append(partial(ops.gemm, x.v, wsc, sc_buf, bias=bsc))
+            resid = sc_buf
+        else:
+            resid = x.v
+        self.fwd.append(partial(ops.gemm, n2, w2, out.v, bias=b2, resid=resid, M=M,
+                                conv=self._conv_desc(h, wd, cout, h, wd, 1, 1, 0, cout)))
+        rec = dict(kind="resnet", x=x, out=out, h1=h1, gn1=gn1, gn2=gn2, cin=cin, cout=cout, h=h, wd=wd,
+                   need_dx=need_dx, name=name)
+        if self.need_backward and need_dx:
+            rec["w2d"] = self._w16(packing.conv3x3_dgrad(w[name + "conv2.weight"]))
+            rec["w1d"] = self._w16(packing.conv3x3_dgrad(w[name + "conv1.weight"]))
+            if wsc is not None:
+                rec["wscd"] = self._w16(w[name + "conv_shortcut.weight"].reshape(cout, cin).t())
+        self.tape.append(rec)
+        return out
+
+    def _resnet_bwd(self, r):
+        if not r["need_dx"]:
+            return
+        x, out, h, wd, cin, cout = r["x"], r["out"], r["h"], r["wd"], r["cin"], r["cout"]
+        M = x.rows
+        dout = out.g
+        assert out.gw, f"resnet {r['name']}: output gradient was never produced"
+        dn2 = self._tmp("dA", M, cout)
+        self.bwd.append(partial(ops.gemm, dout, r["w2d"], dn2, M=M,
+                                conv=self._conv_desc(h, wd, cout, h, wd, 1, 1, 0, dout.stride(0), mode=2)))
+        dh1 = self._tmp("dB", M, cout)
+        self.bwd.append(partial(self._gn_bwd_fn(r["gn2"], dn2), dh1, None))
+        dn1 = self._tmp("dC", M, cin)
+        self.bwd.append(partial(ops.gemm, dh1, r["w1d"], dn1, M=M,
+                                conv=self._conv_desc(h, wd, cout, h, wd, 1, 1, 0, cout, mode=2)))
+        if "wscd" in r:
+            self._contrib(x, lambda o, acc, d=dout, wt=r["wscd"]: ops.gemm(d, wt, o, resid=acc))
+            self._contrib(x, self._gn_bwd_fn(r["gn1"], dn1))
+        else:
+            self._contrib(x, self._gn_bwd_fn(r["gn1"], dn1), extra=dout)
+
+    def _ln(self, xv, name, w):
+        rows, Cc = xv.shape
+        rec = dict(x=xv, gamma=self._w32(w[name + ".weight"]), beta=self._w32(w[name + ".bias"]),
+                   mean=self._buf((rows,), torch.float32), rstd=self._buf((rows,), torch.float32))
+        y = self._buf((rows, Cc))
+        self.fwd.append(partial(ops.layernorm_fwd, xv, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], 1e-5))
+        return y, rec
+
+    def _ln_bwd(self, rec, dy, dx, accum):
+        ops.layernorm_bwd(dy, rec["x"], rec["gamma"], rec["mean"], rec["rstd"], dx, accum=accum)
+
+    def _downsample(self, x: T, Cc, name, w, out_view, h, wd, pad=1):
+        """Downsample2D: 3x3 stride-2 conv; pad=1 (UNet) or pad=0 with bottom/right zero padding (VAE)."""
+        M = x.rows // 4
+        wf = self._w16(packing.conv3x3_fwd(w[name + "weight"]))
+        b = self._w32(w[name + "bias"])
+        out = T(out_view if out_view is not None else self._buf((M, Cc)))
+        self.fwd.append(partial(ops.gemm, x.v, wf, out.v, bias=b, M=M,
+                                conv=self._conv_desc(h, wd, Cc, h // 2, wd // 2, 2, pad, 0, x.v.stride(0))))
+        rec = dict(kind="down", x=x, out=out, C=Cc, h=h, wd=wd, pad=pad)
+        if self.need_backward:
+            rec["wd_"] = self._w16(packing.conv3x3_dgrad(w[name + "weight"]))
+        self.tape.append(rec)
+        return out
+
+    def _downsample_bwd(self, r):
+        x, out, Cc, h, wd = r["x"], r["out"], r["C"], r["h"], r["wd"]
+        assert out.gw
+        desc = self._conv_desc(h // 2, wd // 2, Cc, h, wd, 2, r["pad"], 0, out.g.stride(0), mode=2)
+        self._contrib(x, lambda o, acc, d=out.g, wt=r["wd_"]: ops.gemm(d, wt, o, resid=acc, M=x.rows, conv=desc))
+
+    # ------------------------------------------------------------------ execution
+    def forward(self):
+        for f in self.fwd:
+            f()
+
+    def backward(self):
+        for f in self.bwd:
+            f()

@@ -19,46 +19,22 @@ lists, which makes the step capturable in a hipGraph.
 from __future__ import annotations
 
 from functools import partial
-from typing import Dict, List, Optional
+from typing import Dict
 
 import torch
 
 from .. import ops, packing
 from .. import sd_config as sc
+from .schedule import Schedule, T, rup as _rup
 
 
-class T:
-    """Activation handle: forward view `v`, gradient view `g`, and whether `g` already holds a
-    contribution (tracked in backward *execution* order while the schedule is built)."""
-
-    __slots__ = ("v", "g", "gw", "rows", "cols", "children", "need_grad")
-
-    def __init__(self, v, g=None, need_grad=True):
-        self.v = v
-        self.g = g
-        self.gw = False
-        self.rows, self.cols = v.shape
-        self.children: List["T"] = []
-        self.need_grad = need_grad
-
-
-def _rup(x, m):
-    return (x + m - 1) // m * m
-
-
-class UNetEngine:
+class UNetEngine(Schedule):
     def __init__(self, cfg: sc.UNetConfig, weights: Dict[str, torch.Tensor], batch: int, height: int, width: int,
                  ctx_len: int = 77, device: str = "cuda", need_backward: bool = True):
+        super().__init__(batch, cfg.norm_num_groups, cfg.norm_eps, device, need_backward)
         self.cfg = cfg
-        self.B, self.H, self.W = batch, height, width
+        self.H, self.W = height, width
         self.L = ctx_len
-        self.dev = device
-        self.need_backward = need_backward
-        self.fwd: List = []
-        self.bwd: List = []
-        self.tape: List = []
-        self.bytes = 0
-        self._scratch: Dict[str, torch.Tensor] = {}
         self.nl = cfg.n_cross_layers
         B, L, Dc = batch, ctx_len, cfg.cross_attention_dim
         # inputs / outputs (static buffers)
@@ -71,41 +47,9 @@ class UNetEngine:
         self.pred = self._buf((B * height * width, 8))[:, : cfg.out_channels]
         self.dpred = self._buf((B * height * width, 8), zero=True)[:, : cfg.out_channels]
         self._pack_time_weights(weights)
-        self.gn_ws = self._buf((self._max_gn_ws(),), torch.float32)
         self._build(weights)
         if need_backward:
             self._build_backward()
-
-    # ------------------------------------------------------------------ memory helpers
-    def _buf(self, shape, dtype=torch.float16, zero=False):
-        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
-        self.bytes += t.numel() * t.element_size()
-        return t
-
-    def _tmp(self, name, rows, cols, dtype=torch.float16):
-        """reusable scratch for backward temporaries (single stream => sequential lifetimes)."""
-        key = f"{name}:{dtype}"
-        n = rows * cols
-        cur = self._scratch.get(key)
-        if cur is None or cur.numel() < n:
-            self._scratch[key] = self._buf((n,), dtype)
-            cur = self._scratch[key]
-        return cur[:n].view(rows, cols)
-
-    def _w16(self, t):
-        w = t.to(device=self.dev, dtype=torch.float16).contiguous()
-        self.bytes += w.numel() * 2
-        return w
-
-    def _w32(self, t):
-        w = t.to(device=self.dev, dtype=torch.float32).contiguous()
-        self.bytes += w.numel() * 4
-        return w
-
-    def _max_gn_ws(self):
-        # vneti_groupnorm_ws_floats upper bound: <=256 slabs x 2G partials + 2*B*G finals
-        G = self.cfg.norm_num_groups
-        return self.B * 256 * 2 * G + 2 * self.B * G
 
     # ------------------------------------------------------------------ time embedding
     def _pack_time_weights(self, w):
@@ -139,112 +83,6 @@ class UNetEngine:
         # every consumer applies SiLU to temb first (ResnetBlock2D), so store SiLU(temb) directly
         f.append(partial(ops.gemm, self.t_h, self.w_t2, self.t_emb, bias=self.b_t2, act=ops.ACT_SILU, tile_hint=3))
         f.append(partial(ops.gemm, self.t_emb, self.w_temb_all, self.temb_all, bias=self.b_temb_all, tile_hint=3))
-
-    # ------------------------------------------------------------------ gradient bookkeeping
-    def _grad(self, t: T):
-        if t.g is None:
-            t.g = self._buf((t.rows, t.cols))
-        return t.g
-
-    def _contrib(self, t: T, fn, extra=None):
-        """fn(out, accum) must launch a kernel computing out = result (+ accum)."""
-        g = self._grad(t)
-        if t.gw:
-            if extra is not None:
-                self.bwd.append(partial(ops.add, g, extra, g))
-            self.bwd.append(partial(fn, g, g))
-        else:
-            self.bwd.append(partial(fn, g, extra))
-            t.gw = True
-            for c in t.children:
-                c.gw = True
-
-    # ------------------------------------------------------------------ layer builders
-    def _gn(self, x: T, name, w, eps, silu):
-        Cc = x.cols
-        hw = x.rows // self.B
-        rec = dict(kind="gn", x=x, gamma=self._w32(w[name + ".weight"]), beta=self._w32(w[name + ".bias"]),
-                   mean=self._buf((self.B * self.cfg.norm_num_groups,), torch.float32),
-                   rstd=self._buf((self.B * self.cfg.norm_num_groups,), torch.float32), silu=silu, hw=hw)
-        y = self._buf((x.rows, Cc))
-        self.fwd.append(partial(ops.groupnorm_fwd, x.v, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"],
-                                self.gn_ws, self.B, hw, Cc, self.cfg.norm_num_groups, eps, silu))
-        return y, rec
-
-    def _gn_bwd_fn(self, rec, dy):
-        x = rec["x"]
-        return lambda out, accum: ops.groupnorm_bwd(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
-                                                    self.gn_ws, self.B, rec["hw"], x.cols, self.cfg.norm_num_groups,
-                                                    rec["silu"], accum=accum)
-
-    def _conv_desc(self, Hi, Wi, Ci, Ho, Wo, stride, pad, ups, ldx, mode=1):
-        return dict(mode=mode, Hi=Hi, Wi=Wi, Ci=Ci, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad, pad_l=pad, ups=ups,
-                    ldx=ldx)
-
-    def _resnet(self, x: T, cin, cout, name, w, out_view, h, wd, need_dx=True):
-        cfg = self.cfg
-        M = x.rows
-        n1, gn1 = self._gn(x, name + "norm1", w, cfg.norm_eps, True)
-        w1 = self._w16(packing.conv3x3_fwd(w[name + "conv1.weight"]))
-        b1 = self._w32(w[name + "conv1.bias"])
-        off, n = self.temb_off[name]
-        radd = self.temb_all[:, off:off + n]
-        h1 = T(self._buf((M, cout)))
-        self.fwd.append(partial(ops.gemm, n1, w1, h1.v, bias=b1, rowadd=radd, rows_per_group=h * wd, M=M,
-                                conv=self._conv_desc(h, wd, cin, h, wd, 1, 1, 0, cin)))
-        n2, gn2 = self._gn(h1, name + "norm2", w, cfg.norm_eps, True)
-        w2 = self._w16(packing.conv3x3_fwd(w[name + "conv2.weight"]))
-        b2 = self._w32(w[name + "conv2.bias"])
-        out = T(out_view if out_view is not None else self._buf((M, cout)))
-        wsc = None
-        if cin != cout:
-            wsc = self._w16(w[name + "conv_shortcut.weight"].reshape(cout, cin))
-            bsc = self._w32(w[name + "conv_shortcut.bias"])
-            sc_buf = self._buf((M, cout))
-            self.fwd.append(partial(ops.gemm, x.v, wsc, sc_buf, bias=bsc))
-            resid = sc_buf
-        else:
-            resid = x.v
-        self.fwd.append(partial(ops.gemm, n2, w2, out.v, bias=b2, resid=resid, M=M,
-                                conv=self._conv_desc(h, wd, cout, h, wd, 1, 1, 0, cout)))
-        rec = dict(kind="resnet", x=x, out=out, h1=h1, gn1=gn1, gn2=gn2, cin=cin, cout=cout, h=h, wd=wd,
-                   need_dx=need_dx, name=name)
-        if self.need_backward and need_dx:
-            rec["w2d"] = self._w16(packing.conv3x3_dgrad(w[name + "conv2.weight"]))
-            rec["w1d"] = self._w16(packing.conv3x3_dgrad(w[name + "conv1.weight"]))
-            if wsc is not None:
-                rec["wscd"] = self._w16(w[name + "conv_shortcut.weight"].reshape(cout, cin).t())
-        self.tape.append(rec)
-        return out
-
-    def _resnet_bwd(self, r):
-        if not r["need_dx"]:
-            return
-        x, out, h, wd, cin, cout = r["x"], r["out"], r["h"], r["wd"], r["cin"], r["cout"]
-        M = x.rows
-        dout = out.g
-        assert out.gw, f"resnet {r['name']}: output gradient was never produced"
-        dn2 = self._tmp("dA", M, cout)
-        self.bwd.append(partial(ops.gemm, dout, r["w2d"], dn2, M=M,
-                                conv=self._conv_desc(h, wd, cout, h, wd, 1, 1, 0, dout.stride(0), mode=2)))
-        dh1 = self._tmp("dB", M, cout)
-        self.bwd.append(partial(self._gn_bwd_fn(r["gn2"], dn2), dh1, None))
-        dn1 = self._tmp("dC", M, cin)
-        self.bwd.append(partial(ops.gemm, dh1, r["w1d"], dn1, M=M,
-                                conv=self._conv_desc(h, wd, cout, h, wd, 1, 1, 0, cout, mode=2)))
-        if "wscd" in r:
-            self._contrib(x, lambda o, acc, d=dout, wt=r["wscd"]: ops.gemm(d, wt, o, resid=acc))
-            self._contrib(x, self._gn_bwd_fn(r["gn1"], dn1))
-        else:
-            self._contrib(x, self._gn_bwd_fn(r["gn1"], dn1), extra=dout)
-
-    def _ln(self, xv, name, w):
-        rows, Cc = xv.shape
-        rec = dict(x=xv, gamma=self._w32(w[name + ".weight"]), beta=self._w32(w[name + ".bias"]),
-                   mean=self._buf((rows,), torch.float32), rstd=self._buf((rows,), torch.float32))
-        y = self._buf((rows, Cc))
-        self.fwd.append(partial(ops.layernorm_fwd, xv, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], 1e-5))
-        return y, rec
 
     def _transformer(self, x: T, Cc, heads, name, w, layer_idx, out_view, h, wd, need_dx=True):
         cfg = self.cfg
@@ -325,9 +163,6 @@ class UNetEngine:
         self.tape.append(r)
         return out
 
-    def _ln_bwd(self, rec, dy, dx, accum):
-        ops.layernorm_bwd(dy, rec["x"], rec["gamma"], rec["mean"], rec["rstd"], dx, accum=accum)
-
     def _transformer_bwd(self, r):
         B, L, Cc, heads, D, N = self.B, self.L, r["C"], r["heads"], r["D"], r["N"]
         x, out = r["x"], r["out"]
@@ -398,25 +233,6 @@ class UNetEngine:
         dg = self._tmp("tA", M, Cc)
         bw.append(partial(ops.gemm, dh0, r["w_ind"], dg))
         self._contrib(x, self._gn_bwd_fn(r["gn"], dg), extra=dout)
-
-    def _downsample(self, x: T, Cc, name, w, out_view, h, wd):
-        M = x.rows // 4
-        wf = self._w16(packing.conv3x3_fwd(w[name + "weight"]))
-        b = self._w32(w[name + "bias"])
-        out = T(out_view if out_view is not None else self._buf((M, Cc)))
-        self.fwd.append(partial(ops.gemm, x.v, wf, out.v, bias=b, M=M,
-                                conv=self._conv_desc(h, wd, Cc, h // 2, wd // 2, 2, 1, 0, x.v.stride(0))))
-        rec = dict(kind="down", x=x, out=out, C=Cc, h=h, wd=wd)
-        if self.need_backward:
-            rec["wd_"] = self._w16(packing.conv3x3_dgrad(w[name + "weight"]))
-        self.tape.append(rec)
-        return out
-
-    def _downsample_bwd(self, r):
-        x, out, Cc, h, wd = r["x"], r["out"], r["C"], r["h"], r["wd"]
-        assert out.gw
-        desc = self._conv_desc(h // 2, wd // 2, Cc, h, wd, 2, 1, 0, out.g.stride(0), mode=2)
-        self._contrib(x, lambda o, acc, d=out.g, wt=r["wd_"]: ops.gemm(d, wt, o, resid=acc, M=x.rows, conv=desc))
 
     def _upsample(self, x: T, Cc, name, w, out_view, h, wd):
         M = x.rows * 4
@@ -592,12 +408,3 @@ class UNetEngine:
                 self._downsample_bwd(r)
             elif k == "up":
                 self._upsample_bwd(r)
-
-    # ------------------------------------------------------------------ execution
-    def forward(self):
-        for f in self.fwd:
-            f()
-
-    def backward(self):
-        for f in self.bwd:
-            f()

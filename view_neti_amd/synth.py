@@ -50,44 +50,59 @@ def normal_like(n: int, seed: int) -> np.ndarray:
     return acc * np.float32(np.sqrt(3.0 / 4.0))
 
 
+def uniform_pm1_torch(n: int, seed: int, device="cpu") -> torch.Tensor:
+    """Bit-identical to uniform_pm1 but in torch int64 arithmetic (wraps mod 2^64, low 32 bits
+    exact), so it can run multi-threaded on CPU or on the GPU."""
+    M = 0xFFFFFFFF
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    step = 1 << 24
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        sd = (seed + (s >> 24) * 0x632BE5AB) & M
+        x = torch.arange(s, e, dtype=torch.int64, device=device)
+        x = (x * 0x9E3779B1 + sd) & M
+        x = x ^ (x >> 16)
+        x = (x * 0x7FEB352D) & M
+        x = x ^ (x >> 15)
+        x = (x * 0x846CA68B) & M
+        x = x ^ (x >> 16)
+        out[s:e] = (x >> 8).to(torch.float32) * (2.0 ** -23) - 1.0
+    return out
+
+
 def _name_seed(name: str, seed: int) -> int:
     return (zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF
 
 
-def make_tensor(name: str, shape, seed: int) -> torch.Tensor:
+def make_tensor(name: str, shape, seed: int, device="cpu") -> torch.Tensor:
     n = int(np.prod(shape))
-    u = uniform_pm1(n, _name_seed(name, seed))
+    u = uniform_pm1_torch(n, _name_seed(name, seed), device)
     if name.endswith("embedding.weight"):
-        u *= np.float32(0.02 * np.sqrt(3.0))
+        u = u * float(np.float32(0.02 * np.sqrt(3.0)))
     elif name.endswith(".bias"):
-        u *= np.float32(0.02)
+        u = u * float(np.float32(0.02))
     elif len(shape) == 1:  # norm gains
-        u = np.float32(1.0) + np.float32(0.02) * u
+        u = 1.0 + float(np.float32(0.02)) * u
     else:
         fan_in = int(np.prod(shape[1:]))
-        u *= np.float32(np.sqrt(3.0 / fan_in))
-    return torch.from_numpy(u.reshape(shape))
+        u = u * float(np.float32(np.sqrt(3.0 / fan_in)))
+    return u.reshape(shape)
 
 
-def make_state_dict(shapes: sc.Shapes, seed: int) -> Dict[str, torch.Tensor]:
-    sd = {}
-    for name, shape in shapes.items():
-        t = make_tensor(name, shape, seed)
-        # norm layers: "<x>.weight" of 1-D shape are gains, "<x>.bias" shifts — handled in make_tensor
-        sd[name] = t
-    return sd
+def make_state_dict(shapes: sc.Shapes, seed: int, device="cpu") -> Dict[str, torch.Tensor]:
+    return {name: make_tensor(name, shape, seed, device) for name, shape in shapes.items()}
 
 
-def unet_weights(cfg: sc.UNetConfig, seed: int = 1234):
-    return make_state_dict(sc.unet_shapes(cfg), seed)
+def unet_weights(cfg: sc.UNetConfig, seed: int = 1234, device="cpu"):
+    return make_state_dict(sc.unet_shapes(cfg), seed, device)
 
 
-def vae_weights(cfg: sc.VAEConfig, seed: int = 1234):
-    return make_state_dict(sc.vae_encoder_shapes(cfg), seed + 1)
+def vae_weights(cfg: sc.VAEConfig, seed: int = 1234, device="cpu"):
+    return make_state_dict(sc.vae_encoder_shapes(cfg), seed + 1, device)
 
 
-def clip_weights(cfg: sc.CLIPTextConfig, seed: int = 1234):
-    return make_state_dict(sc.clip_text_shapes(cfg), seed + 2)
+def clip_weights(cfg: sc.CLIPTextConfig, seed: int = 1234, device="cpu"):
+    return make_state_dict(sc.clip_text_shapes(cfg), seed + 2, device)
 
 
 # ----------------------------------------------------------------------------------------------
