@@ -195,6 +195,51 @@ int vneti_mse_loss_grad(const void* pred, long long ldp, const float* target, vo
 int vneti_adamw_flat(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
                      float* scaler, int* step, int growth_interval, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * NeTI text path
+ * ------------------------------------------------------------------------------------------ */
+/* NeTIMapper (arch_view_net=15) for R = n_layers*batch rows at once
+ * (models/neti_mapper.py:165-197): data[R][nfeat] are the [-1,1]-scaled conditioning inputs
+ * (t, l[, 12 camera params]); w_enc[enc_dim/2][nfeat] the Fourier frequencies
+ * (models/positional_encoding.py:146-195); params the flat f32 bucket in state_dict order
+ * (net.0.{weight,bias}, net.1.*, net.3.*, net.4.*, output_layer.0.*).  hidden_mask (optional,
+ * [R][hidden] of 0/1) expresses nested dropout / truncation (:401-414).  norm_scale <= 0 disables
+ * the output normalisation (:434-436).  word/bypass: f32 [R][D]. */
+long long vneti_mapper_num_params(int enc_dim, int hidden, int D, int has_bypass);
+long long vneti_mapper_save_floats(int R, int enc_dim, int hidden);
+long long vneti_mapper_rowgrad_floats(int R, int hidden, int D, int has_bypass);
+int vneti_mapper_fwd(const float* params, const float* data, int nfeat, const float* w_enc,
+                     const float* hidden_mask, float norm_scale, float* word, float* bypass,
+                     float* save, int R, int enc_dim, int hidden, int D, int has_bypass, void* stream);
+/* parameter gradients (the only wgrad of the whole train step).  d(word) for mapper row r is
+ * read from dword_src + dword_rows[r]*ld_src (the placeholder rows of the embedding gradient). */
+int vneti_mapper_bwd(const float* params, const float* hidden_mask, float norm_scale,
+                     const float* word, const float* dword_src, const int* dword_rows,
+                     long long ld_src, const float* dbypass, const float* save, float* rowgrads,
+                     float* grads, int accumulate, int R, int enc_dim, int hidden, int D,
+                     int has_bypass, void* stream);
+/* NeTICLIPTextEmbeddings.forward (models/net_clip_text_embedding.py:34-137) for all layers:
+ * X[(l,b,pos)][D] f32 = (pos == pos_obj[b] ? word_obj[(l,b)] : pos == pos_view[b] ? word_view : E[ids[b][pos]]) + P[pos] */
+int vneti_text_embed(const float* tok_emb, const float* pos_emb, const void* ids_i64,
+                     const int* pos_obj, const float* word_obj, const int* pos_view,
+                     const float* word_view, float* X, int nl, int Bn, int L, int D, void* stream);
+/* textual bypass + final_layer_norm on both variants (models/neti_clip_text_encoder.py:121-185,
+ * constrained bypass): ctx_k = LN(last), ctx_v = LN(last with placeholder rows x + alpha b/|b| |x|) */
+int vneti_text_final_fwd(const float* last, const float* gamma, const float* beta, float eps,
+                         const int* pos_obj, const float* bypass_obj, float alpha_obj,
+                         const int* pos_view, const float* bypass_view, float alpha_view,
+                         void* ctx_k, void* ctx_v, int nl, int Bn, int L, int D, void* stream);
+int vneti_text_final_bwd(const float* last, const float* gamma, float eps, const int* pos_obj,
+                         const float* bypass_obj, float alpha_obj, float* dbypass_obj,
+                         const int* pos_view, const float* bypass_view, float alpha_view,
+                         float* dbypass_view, const void* dctx_k, const void* dctx_v, float* dX,
+                         int nl, int Bn, int L, int D, void* stream);
+/* conditioning inputs of the mapper for every (layer, sample) row:
+ * data[(l,b)] = [t_b/1000*2-1, l/nl*2-1, view_params[b][0..nv)]  (models/neti_mapper.py:545-562) */
+int vneti_mapper_inputs(const void* timesteps_i64, const float* view_params, int nv, float* data,
+                        int nl, int Bn, void* stream);
+int vneti_cast_f32_f16(const float* x, void* y, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,91 @@
+"""Text engine (batched 16-pass CLIP + fused NeTI mapper) vs the CPU oracle: both contexts and
+the mapper parameter gradients (the only weight gradients of the train step)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+@pytest.mark.parametrize("with_view", [False, True])
+def test_text_engine_tiny(with_view):
+    from oracle import sd_ref as R
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.text import MapperState, TextEngine, flatten_mapper_state
+    from view_neti_amd.mapper import fourier_frequencies
+    dev = "cuda"
+    cfg = sc.tiny().clip
+    D, L, nl, B = cfg.hidden_size, cfg.max_positions, 16, 2
+    w = synth.clip_weights(cfg)
+    # matmul operands are fp16 on the GPU: round those weights once for both sides
+    wr = {k: (v.half().float() if (k.endswith("weight") and v.dim() == 2 and "embedding" not in k) else v)
+          for k, v in w.items()}
+    ph_obj, ph_view = cfg.vocab_size - 3, cfg.vocab_size - 4
+    ids = synth.input_ids(B, ph_obj, cfg.vocab_size, L, view_placeholder_id=ph_view if with_view else None)
+    ids[1] = torch.roll(ids[1], 3)  # different placeholder positions per sample
+    t = torch.tensor([17, 803])
+    gen = torch.Generator().manual_seed(3)
+
+    def rand_mapper(nfeat_sigmas):
+        sd = {"net.0.weight": torch.randn(64, 64, generator=gen) * 0.15, "net.0.bias": torch.randn(64, generator=gen) * 0.1,
+              "net.1.weight": 1 + 0.1 * torch.randn(64, generator=gen), "net.1.bias": 0.1 * torch.randn(64, generator=gen),
+              "net.3.weight": torch.randn(64, 64, generator=gen) * 0.15, "net.3.bias": torch.randn(64, generator=gen) * 0.1,
+              "net.4.weight": 1 + 0.1 * torch.randn(64, generator=gen), "net.4.bias": 0.1 * torch.randn(64, generator=gen),
+              "output_layer.0.weight": torch.randn(2 * D, 64, generator=gen) * 0.15,
+              "output_layer.0.bias": torch.randn(2 * D, generator=gen) * 0.1}
+        return sd, fourier_frequencies(nfeat_sigmas, 64, 0, preserve_rng=True)
+
+    sdo, w_enc_o = rand_mapper([0.03, 2.0])
+    ctx_k = torch.zeros(nl, B * L, D, dtype=torch.float16, device=dev)
+    ctx_v = torch.zeros_like(ctx_k)
+    dk = (synth.gaussian((nl, B * L, D), 11) * 0.5).half()
+    dv = (synth.gaussian((nl, B * L, D), 12) * 0.5).half()
+    ts = t.to(dev)
+    po = flatten_mapper_state(sdo).to(dev)
+    go = torch.zeros_like(po)
+    mo = MapperState(po, w_enc_o.to(dev), 0.4, 0.2)
+    kw = {}
+    view = None
+    if with_view:
+        sdv, w_enc_v = rand_mapper([0.03, 2.0] + [0.5] * 12)
+        vparams = torch.rand(B, 12, generator=gen) * 2 - 1
+        pv = flatten_mapper_state(sdv).to(dev)
+        gv = torch.zeros_like(pv)
+        kw = dict(mapper_view=MapperState(pv, w_enc_v.to(dev), 0.35, 0.3), grads_view=gv)
+    eng = TextEngine(cfg, wr, nl, B, ts, ctx_k, ctx_v, dk.to(dev), dv.to(dev), mo, go, **kw)
+    eng.set_batch(ids, torch.full((B,), ph_obj), torch.full((B,), ph_view) if with_view else None,
+                  vparams if with_view else None)
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    # ---- oracle ----
+    p_o = {k: v.clone().requires_grad_(True) for k, v in sdo.items()}
+    if with_view:
+        p_v = {k: v.clone().requires_grad_(True) for k, v in sdv.items()}
+        view = dict(p=p_v, w_enc=w_enc_v, norm_scale=0.35, placeholder=torch.full((B,), ph_view), params=vparams,
+                    alpha=0.3)
+    hs = R.text_conditioning(wr, cfg, p_o, w_enc_o, 0.4, ids, torch.full((B,), ph_obj), t, alpha=0.2, n_layers=nl,
+                             view=view)
+    rk = torch.stack([hs[f"CONTEXT_TENSOR_{i}"] for i in range(nl)]).reshape(nl, B * L, D)
+    rv = torch.stack([hs[f"CONTEXT_TENSOR_BYPASS_{i}"] for i in range(nl)]).reshape(nl, B * L, D)
+    ek, ev = _rel(ctx_k, rk.detach()), _rel(ctx_v, rv.detach())
+    print(f"[text view={with_view}] ctx_k rel {ek:.3e}  ctx_v rel {ev:.3e}")
+    assert ek < 5e-3 and ev < 5e-3
+    ((rk * dk.float()).sum() + (rv * dv.float()).sum()).backward()
+    ref_g = flatten_mapper_state({k: v.grad for k, v in p_o.items()})
+    eg = _rel(go, ref_g)
+    cos = torch.nn.functional.cosine_similarity(go.float().cpu(), ref_g, dim=0).item()
+    print(f"[text view={with_view}] object-mapper grad rel {eg:.3e} cos {cos:.6f} |g| {ref_g.norm():.3e}")
+    assert math.isfinite(eg) and eg < 3e-2 and cos > 0.999
+    if with_view:
+        ref_gv = flatten_mapper_state({k: v.grad for k, v in p_v.items()})
+        egv = _rel(gv, ref_gv)
+        cosv = torch.nn.functional.cosine_similarity(gv.float().cpu(), ref_gv, dim=0).item()
+        print(f"[text view] view-mapper grad rel {egv:.3e} cos {cosv:.6f}")
+        assert egv < 3e-2 and cosv > 0.999

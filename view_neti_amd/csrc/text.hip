@@ -1,0 +1,649 @@
+// NeTI text-path kernels: the fused mapper (the only trainable network of the train step),
+// the placeholder-overwriting embedding lookup, and the textual-bypass + final LayerNorm pair.
+//
+// Reference code restated here (see oracle/sd_ref.py for the line-by-line CPU version):
+//   models/neti_mapper.py:165-197,368-438,542-578  NeTIMapper.forward (arch_view_net = 15)
+//   models/positional_encoding.py:174-195          FourierPositionalEncodingNDims.forward
+//   models/net_clip_text_embedding.py:34-137       token embed -> overwrite placeholder rows -> + position
+//   models/neti_clip_text_encoder.py:121-185       bypass injection on a clone + final_layer_norm x2
+// The reference runs these once per UNet cross-attention layer (16 python passes with ~100 host
+// syncs, training/coach.py:289-305); here all (layer, sample) pairs are rows of one launch.
+#include "common.h"
+#include "../../include/vneti.h"
+
+namespace {
+
+constexpr int MAXH = 128;  // max hidden width of the mapper MLP
+
+struct MapperParams {
+  // offsets (in floats) into the flat parameter / gradient bucket, state_dict order:
+  // net.0.weight [hd][E], net.0.bias, net.1.weight, net.1.bias, net.3.weight [hd][hd], net.3.bias,
+  // net.4.weight, net.4.bias, output_layer.0.weight [OD][hd], output_layer.0.bias [OD]
+  int w0, b0, g1, be1, w3, b3, g2, be2, wo, bo;
+  int E, hd, OD, D;  // E = encoding dim (64), OD = 2*D with bypass else D
+};
+
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }
+
+__device__ void block_layernorm(float* z, const float* gamma, const float* beta, float* xh, float* y, int hd,
+                                float* stat) {
+  // z[hd] in LDS -> xh (normalised), y = xh*gamma+beta; stat[0]=rstd.  eps = 1e-5 (nn.LayerNorm default)
+  if (threadIdx.x == 0) {
+    float m = 0.f;
+    for (int i = 0; i < hd; ++i) m += z[i];
+    m /= hd;
+    float v = 0.f;
+    for (int i = 0; i < hd; ++i) v += (z[i] - m) * (z[i] - m);
+    stat[0] = m;
+    stat[1] = rsqrtf(v / hd + 1e-5f);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < hd) {
+    float h = (z[threadIdx.x] - stat[0]) * stat[1];
+    xh[threadIdx.x] = h;
+    y[threadIdx.x] = h * gamma[threadIdx.x] + beta[threadIdx.x];
+  }
+  __syncthreads();
+}
+
+// one block (256 threads) per mapper row r = (layer, sample)
+__global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const float* __restrict__ params,
+                                                         const float* __restrict__ data, int nfeat,
+                                                         const float* __restrict__ w_enc,
+                                                         const float* __restrict__ hmask, float norm_scale,
+                                                         float* __restrict__ word, float* __restrict__ bypass,
+                                                         float* __restrict__ save) {
+  __shared__ float enc[MAXH], z[MAXH], xh[MAXH], y[MAXH], a[MAXH], stat[2], red[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int E = mp.E, hd = mp.hd, D = mp.D;
+  // per-row save area: enc[E] | xh1[hd] | a1[hd] | xh2[hd] | a2m[hd] | rstd1, rstd2, wnorm, pad
+  float* sv = save + (long long)r * (E + 4 * hd + 4);
+  if (tid < E / 2) {
+    float p = 0.f;
+    for (int f = 0; f < nfeat; ++f) p += w_enc[tid * nfeat + f] * data[r * nfeat + f];
+    enc[tid] = sinf(p);
+    enc[E / 2 + tid] = cosf(p);
+  }
+  __syncthreads();
+  if (tid < E) sv[tid] = enc[tid];
+  if (tid < hd) {
+    float s = params[mp.b0 + tid];
+    const float* wr = params + mp.w0 + tid * E;
+    for (int i = 0; i < E; ++i) s += wr[i] * enc[i];
+    z[tid] = s;
+  }
+  __syncthreads();
+  block_layernorm(z, params + mp.g1, params + mp.be1, xh, y, hd, stat);
+  if (tid < hd) {
+    a[tid] = leaky(y[tid]);
+    sv[E + tid] = xh[tid];
+    sv[E + hd + tid] = a[tid];
+  }
+  if (tid == 0) sv[E + 4 * hd] = stat[1];
+  __syncthreads();
+  if (tid < hd) {
+    float s = params[mp.b3 + tid];
+    const float* wr = params + mp.w3 + tid * hd;
+    for (int i = 0; i < hd; ++i) s += wr[i] * a[i];
+    z[tid] = s;
+  }
+  __syncthreads();
+  block_layernorm(z, params + mp.g2, params + mp.be2, xh, y, hd, stat);
+  if (tid < hd) {
+    float v = leaky(y[tid]);
+    if (hmask) v *= hmask[r * hd + tid];
+    a[tid] = v;
+    sv[E + 2 * hd + tid] = xh[tid];
+    sv[E + 3 * hd + tid] = v;
+  }
+  if (tid == 0) sv[E + 4 * hd + 1] = stat[1];
+  __syncthreads();
+  // output layer
+  float sq = 0.f;
+  for (int o = tid; o < mp.OD; o += 256) {
+    float s = params[mp.bo + o];
+    const float* wr = params + mp.wo + (long long)o * hd;
+    for (int i = 0; i < hd; ++i) s += wr[i] * a[i];
+    if (o < D) {
+      word[(long long)r * D + o] = s;
+      sq += s * s;
+    } else {
+      bypass[(long long)r * D + (o - D)] = s;
+    }
+  }
+  sq = wave_sum(sq);
+  if ((tid & 63) == 0) red[tid >> 6] = sq;
+  __syncthreads();
+  const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  if (tid == 0) sv[E + 4 * hd + 2] = nrm;
+  if (norm_scale > 0.f) {
+    const float f = norm_scale / fmaxf(nrm, 1e-12f);  // F.normalize(eps=1e-12) * norm_scale
+    for (int o = tid; o < D; o += 256) word[(long long)r * D + o] *= f;
+  }
+}
+
+// backward stage 1: per row, from (d_word, d_bypass) down to the pre-LayerNorm gradients.
+// rowgrads layout per row: dout[OD] | dz2[hd] | dy2[hd] | dz1[hd] | dy1[hd]
+__global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, const float* __restrict__ params,
+                                                              const float* __restrict__ hmask, float norm_scale,
+                                                              const float* __restrict__ word,
+                                                              const float* __restrict__ dword_src,
+                                                              const int* __restrict__ dword_rows, long long ld_src,
+                                                              const float* __restrict__ dbypass,
+                                                              const float* __restrict__ save,
+                                                              float* __restrict__ rowgrads) {
+  __shared__ float dout[2048 + 64], part[4][MAXH], dz[MAXH], da[MAXH], red[4], st[2];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int E = mp.E, hd = mp.hd, D = mp.D, OD = mp.OD;
+  const float* sv = save + (long long)r * (E + 4 * hd + 4);
+  float* rg = rowgrads + (long long)r * (OD + 4 * hd);
+  const float* dw = dword_src + (long long)dword_rows[r] * ld_src;
+  // ---- through F.normalize * norm_scale ----
+  float dot = 0.f;
+  if (norm_scale > 0.f)
+    for (int o = tid; o < D; o += 256) dot += (word[(long long)r * D + o] / norm_scale) * dw[o];
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  __syncthreads();
+  dot = red[0] + red[1] + red[2] + red[3];
+  const float nrm = fmaxf(sv[E + 4 * hd + 2], 1e-12f);
+  for (int o = tid; o < OD; o += 256) {
+    float g;
+    if (o < D) {
+      g = dw[o];
+      if (norm_scale > 0.f) g = (norm_scale / nrm) * (g - (word[(long long)r * D + o] / norm_scale) * dot);
+    } else {
+      g = dbypass ? dbypass[(long long)r * D + (o - D)] : 0.f;
+    }
+    dout[o] = g;
+    rg[o] = g;
+  }
+  __syncthreads();
+  // ---- da2m[j] = sum_o Wout[o][j] dout[o] ----
+  {
+    const int j = tid % hd, p = tid / hd, np = (256 / hd) < 4 ? (256 / hd) : 4;
+    float s = 0.f;
+    if (p < np)
+      for (int o = p; o < OD; o += np) s += params[mp.wo + (long long)o * hd + j] * dout[o];
+    if (p < 4) part[p][j] = s;
+    __syncthreads();
+    if (tid < hd) {
+      float t = 0.f;
+      for (int q = 0; q < np && q < 4; ++q) t += part[q][tid];
+      if (hmask) t *= hmask[r * hd + tid];
+      // leaky backward needs the pre-activation sign: y2 = xh2*g2 + be2
+      float xh2 = sv[E + 2 * hd + tid];
+      float y2 = xh2 * params[mp.g2 + tid] + params[mp.be2 + tid];
+      float dy = t * (y2 > 0.f ? 1.f : 0.01f);
+      rg[OD + hd + tid] = dy;            // dy2
+      da[tid] = dy * params[mp.g2 + tid];  // dxhat2
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float m1 = 0.f, m2 = 0.f;
+      for (int i = 0; i < hd; ++i) {
+        m1 += da[i];
+        m2 += da[i] * sv[E + 2 * hd + i];
+      }
+      st[0] = m1 / hd;
+      st[1] = m2 / hd;
+    }
+    __syncthreads();
+    if (tid < hd) {
+      float v = sv[E + 4 * hd + 1] * (da[tid] - st[0] - sv[E + 2 * hd + tid] * st[1]);
+      dz[tid] = v;
+      rg[OD + tid] = v;  // dz2
+    }
+    __syncthreads();
+  }
+  // ---- da1[i] = sum_j W3[j][i] dz2[j] ; LN1 / leaky backward ----
+  if (tid < hd) {
+    float s = 0.f;
+    for (int j = 0; j < hd; ++j) s += params[mp.w3 + j * hd + tid] * dz[j];
+    float xh1 = sv[E + tid];
+    float y1 = xh1 * params[mp.g1 + tid] + params[mp.be1 + tid];
+    float dy = s * (y1 > 0.f ? 1.f : 0.01f);
+    rg[OD + 3 * hd + tid] = dy;  // dy1
+    da[tid] = dy * params[mp.g1 + tid];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m1 = 0.f, m2 = 0.f;
+    for (int i = 0; i < hd; ++i) {
+      m1 += da[i];
+      m2 += da[i] * sv[E + i];
+    }
+    st[0] = m1 / hd;
+    st[1] = m2 / hd;
+  }
+  __syncthreads();
+  if (tid < hd) rg[OD + 2 * hd + tid] = sv[E + 4 * hd] * (da[tid] - st[0] - sv[E + tid] * st[1]);  // dz1
+}
+
+// backward stage 2: one thread per parameter, summing the per-row outer products over R rows.
+__global__ __launch_bounds__(256) void mapper_bwd_reduce_kernel(MapperParams mp, int R,
+                                                                const float* __restrict__ save,
+                                                                const float* __restrict__ rowgrads,
+                                                                float* __restrict__ grads, int nparams,
+                                                                int accumulate) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= nparams) return;
+  const int E = mp.E, hd = mp.hd, OD = mp.OD;
+  const int ssz = E + 4 * hd + 4, gsz = OD + 4 * hd;
+  // which tensor?
+  int sa, sb;        // (offset in save row or -1 for "1"), (offset in rowgrads row)
+  if (p >= mp.bo) {  // output bias
+    sa = -1;
+    sb = p - mp.bo;
+  } else if (p >= mp.wo) {
+    int o = (p - mp.wo) / hd, j = (p - mp.wo) % hd;
+    sa = E + 3 * hd + j;  // a2m
+    sb = o;
+  } else if (p >= mp.be2) {
+    sa = -1;
+    sb = OD + hd + (p - mp.be2);  // dy2
+  } else if (p >= mp.g2) {
+    sa = E + 2 * hd + (p - mp.g2);  // xh2
+    sb = OD + hd + (p - mp.g2);
+  } else if (p >= mp.b3) {
+    sa = -1;
+    sb = OD + (p - mp.b3);  // dz2
+  } else if (p >= mp.w3) {
+    int j = (p - mp.w3) / hd, i = (p - mp.w3) % hd;
+    sa = E + hd + i;  // a1
+    sb = OD + j;
+  } else if (p >= mp.be1) {
+    sa = -1;
+    sb = OD + 3 * hd + (p - mp.be1);  // dy1
+  } else if (p >= mp.g1) {
+    sa = E + (p - mp.g1);  // xh1
+    sb = OD + 3 * hd + (p - mp.g1);
+  } else if (p >= mp.b0) {
+    sa = -1;
+    sb = OD + 2 * hd + (p - mp.b0);  // dz1
+  } else {
+    int j = (p - mp.w0) / E, i = (p - mp.w0) % E;
+    sa = i;  // enc
+    sb = OD + 2 * hd + j;
+  }
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) {
+    float a = sa >= 0 ? save[(long long)r * ssz + sa] : 1.f;
+    s += a * rowgrads[(long long)r * gsz + sb];
+  }
+  grads[p] = accumulate ? grads[p] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// text embeddings: X[(l,b,pos)] = (pos == placeholder pos ? mapper word[(l,b)] : E[id]) + P[pos]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_embed_kernel(const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos_emb,
+                                                         const long long* __restrict__ ids,
+                                                         const int* __restrict__ pos_obj,
+                                                         const float* __restrict__ word_obj,
+                                                         const int* __restrict__ pos_view,
+                                                         const float* __restrict__ word_view, float* __restrict__ X,
+                                                         int nl, int Bn, int L, int D) {
+  const int d4 = D / 4;
+  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)nl * Bn * L * d4;
+  if (gid >= total) return;
+  int c = (int)(gid % d4) * 4;
+  long long row = gid / d4;
+  int pos = (int)(row % L);
+  int b = (int)((row / L) % Bn);
+  int l = (int)(row / ((long long)L * Bn));
+  const float* src = tok_emb + ids[b * L + pos] * (long long)D;
+  if (pos_obj && pos_obj[b] == pos) src = word_obj + ((long long)l * Bn + b) * D;
+  if (pos_view && pos_view[b] == pos) src = word_view + ((long long)l * Bn + b) * D;  // view overwrites last, as in the reference
+  f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+  f32x4 p = *reinterpret_cast<const f32x4*>(pos_emb + (long long)pos * D + c);
+  *reinterpret_cast<f32x4*>(X + row * D + c) = v + p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// final LayerNorm of the last hidden state (-> key context) and of its bypass-injected clone
+// (-> value context).  One wave per row; only placeholder rows differ between the two.
+// constrained bypass: new = x + alpha * b/|b| * |x|   (neti_clip_text_encoder.py:138-143)
+// ---------------------------------------------------------------------------------------------
+constexpr int TMAX = 4;  // chunks of 8 per lane -> D <= 2048
+
+__device__ __forceinline__ void row_load(const float* p, int D, int lane, float v[TMAX][8]) {
+#pragma unroll
+  for (int i = 0; i < TMAX; ++i) {
+    int c = lane + 64 * i;
+    if (c * 8 < D) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(p + c * 8), b = *reinterpret_cast<const f32x4*>(p + c * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[i][j] = a[j];
+        v[i][4 + j] = b[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+}
+__device__ __forceinline__ float row_dot(const float a[TMAX][8], const float b[TMAX][8]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < TMAX; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a[i][j] * b[i][j];
+  return wave_sum(s);
+}
+__device__ __forceinline__ void row_stats(const float v[TMAX][8], int D, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < TMAX; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[i][j];
+  mean = wave_sum(s) / D;
+  float q = 0.f;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < TMAX; ++i)
+    if ((lane + 64 * i) * 8 < D)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q += (v[i][j] - mean) * (v[i][j] - mean);
+  rstd = rsqrtf(wave_sum(q) / D + eps);
+}
+__device__ __forceinline__ void row_ln_store(const float v[TMAX][8], int D, int lane, float mean, float rstd,
+                                             const float* gamma, const float* beta, half_t* out) {
+#pragma unroll
+  for (int i = 0; i < TMAX; ++i) {
+    int c = lane + 64 * i;
+    if (c * 8 < D) {
+      half8 h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (half_t)((v[i][j] - mean) * rstd * gamma[c * 8 + j] + beta[c * 8 + j]);
+      *reinterpret_cast<half8*>(out + c * 8) = h;
+    }
+  }
+}
+// dx = LayerNorm input-gradient for upstream gradient dy (f16 row) at input v
+__device__ __forceinline__ void row_ln_bwd(const float v[TMAX][8], const half_t* dy, int D, int lane, float eps,
+                                           const float* gamma, float g[TMAX][8]) {
+  float mean, rstd;
+  row_stats(v, D, eps, mean, rstd);
+  float xh[TMAX][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < TMAX; ++i) {
+    int c = lane + 64 * i;
+    if (c * 8 < D) {
+      half8 d = *reinterpret_cast<const half8*>(dy + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[i][j] = (v[i][j] - mean) * rstd;
+        g[i][j] = (float)d[j] * gamma[c * 8 + j];
+        s1 += g[i][j];
+        s2 += g[i][j] * xh[i][j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[i][j] = 0.f;
+        g[i][j] = 0.f;
+      }
+    }
+  }
+  s1 = wave_sum(s1) / D;
+  s2 = wave_sum(s2) / D;
+#pragma unroll
+  for (int i = 0; i < TMAX; ++i)
+    if ((lane + 64 * i) * 8 < D)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[i][j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+}
+
+struct BypassArgs {
+  const int* pos;      // [B] placeholder position per sample (or null)
+  const float* b;      // [nl*B][D] bypass vectors
+  float* db;           // [nl*B][D] gradient (backward only)
+  float alpha;
+};
+
+__global__ __launch_bounds__(256) void text_final_fwd_kernel(const float* __restrict__ last,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             BypassArgs obj, BypassArgs view,
+                                                             half_t* __restrict__ ctx_k, half_t* __restrict__ ctx_v,
+                                                             int nl, int Bn, int L, int D) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long long)nl * Bn * L) return;
+  const int pos = (int)(row % L);
+  const int b = (int)((row / L) % Bn);
+  const int l = (int)(row / ((long long)L * Bn));
+  float x[TMAX][8];
+  row_load(last + row * D, D, lane, x);
+  float mean, rstd;
+  row_stats(x, D, eps, mean, rstd);
+  row_ln_store(x, D, lane, mean, rstd, gamma, beta, ctx_k + row * D);
+  bool changed = false;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const BypassArgs& a = which == 0 ? obj : view;
+    if (a.pos && a.pos[b] == pos) {
+      float bv[TMAX][8];
+      row_load(a.b + ((long long)l * Bn + b) * D, D, lane, bv);
+      const float nb = sqrtf(row_dot(bv, bv)), nx = sqrtf(row_dot(x, x));
+      const float f = a.alpha * nx / nb;
+#pragma unroll
+      for (int i = 0; i < TMAX; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[i][j] += f * bv[i][j];
+      changed = true;
+    }
+  }
+  if (changed) row_stats(x, D, eps, mean, rstd);
+  row_ln_store(x, D, lane, mean, rstd, gamma, beta, ctx_v + row * D);
+}
+
+// dX[row] (f32) from dctx_k, dctx_v (f16); placeholder rows also produce d(bypass).
+__global__ __launch_bounds__(256) void text_final_bwd_kernel(const float* __restrict__ last,
+                                                             const float* __restrict__ gamma, float eps,
+                                                             BypassArgs obj, BypassArgs view,
+                                                             const half_t* __restrict__ dctx_k,
+                                                             const half_t* __restrict__ dctx_v,
+                                                             float* __restrict__ dX, int nl, int Bn, int L, int D) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long long)nl * Bn * L) return;
+  const int pos = (int)(row % L);
+  const int b = (int)((row / L) % Bn);
+  const int l = (int)(row / ((long long)L * Bn));
+  float x[TMAX][8], g1[TMAX][8];
+  row_load(last + row * D, D, lane, x);
+  row_ln_bwd(x, dctx_k + row * D, D, lane, eps, gamma, g1);
+  const bool is_obj = obj.pos && obj.pos[b] == pos;
+  const bool is_view = view.pos && view.pos[b] == pos;
+  float g2[TMAX][8];
+  if (!is_obj && !is_view) {
+    row_ln_bwd(x, dctx_v + row * D, D, lane, eps, gamma, g2);
+  } else {
+    // a row is the placeholder of at most one mapper (object and view tokens sit at different positions)
+    const BypassArgs& a = is_obj ? obj : view;
+    float bv[TMAX][8], nw[TMAX][8];
+    row_load(a.b + ((long long)l * Bn + b) * D, D, lane, bv);
+    const float nb = sqrtf(row_dot(bv, bv)), nx = sqrtf(row_dot(x, x));
+    const float f = a.alpha * nx / nb;
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nw[i][j] = x[i][j] + f * bv[i][j];
+    float g[TMAX][8];
+    row_ln_bwd(nw, dctx_v + row * D, D, lane, eps, gamma, g);
+    // new = x + alpha * u * |x|, u = b/|b|:  dx = g + alpha (u.g) x/|x| ;  db = alpha |x|/|b| (g - u (u.g))
+    const float ug = row_dot(bv, g) / nb;
+    float* dbp = a.db + ((long long)l * Bn + b) * D;
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+      int c = lane + 64 * i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        g2[i][j] = g[i][j] + a.alpha * ug * x[i][j] / nx;
+        if (c * 8 < D) dbp[c * 8 + j] = f * (g[i][j] - bv[i][j] / nb * ug);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TMAX; ++i) {
+    int c = lane + 64 * i;
+    if (c * 8 < D) {
+      f32x4 o0 = {g1[i][0] + g2[i][0], g1[i][1] + g2[i][1], g1[i][2] + g2[i][2], g1[i][3] + g2[i][3]};
+      f32x4 o1 = {g1[i][4] + g2[i][4], g1[i][5] + g2[i][5], g1[i][6] + g2[i][6], g1[i][7] + g2[i][7]};
+      *reinterpret_cast<f32x4*>(dX + row * D + c * 8) = o0;
+      *reinterpret_cast<f32x4*>(dX + row * D + c * 8 + 4) = o1;
+    }
+  }
+}
+
+// data[(l,b)] = [ t_b/1000*2-1, l/nl*2-1, view_params[b][0..nv) ]  (neti_mapper.py:545-562)
+__global__ void mapper_inputs_kernel(const long long* __restrict__ t, const float* __restrict__ view_params, int nv,
+                                     float* __restrict__ data, int nl, int Bn) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int nf = 2 + nv;
+  if (gid >= nl * Bn * nf) return;
+  int f = gid % nf;
+  int r = gid / nf;
+  int b = r % Bn, l = r / Bn;
+  float v;
+  if (f == 0) v = (float)t[b] / 1000.f * 2.f - 1.f;
+  else if (f == 1) v = (float)l / (float)nl * 2.f - 1.f;
+  else v = view_params[b * nv + (f - 2)];
+  data[gid] = v;
+}
+
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y,
+                                                           long long n8) {
+  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n8) return;
+  f32x4 a = *reinterpret_cast<const f32x4*>(x + gid * 8), b = *reinterpret_cast<const f32x4*>(x + gid * 8 + 4);
+  half8 h = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+  *reinterpret_cast<half8*>(y + gid * 8) = h;
+}
+
+int fill_mp(MapperParams& mp, int E, int hd, int D, int has_bypass) {
+  if (E <= 0 || E > MAXH || E % 2 || hd <= 0 || hd > MAXH || 256 % hd != 0 || D <= 0) return -1;
+  mp.E = E;
+  mp.hd = hd;
+  mp.D = D;
+  mp.OD = has_bypass ? 2 * D : D;
+  if (mp.OD > 2048 + 64) return -1;
+  int o = 0;
+  mp.w0 = o; o += hd * E;
+  mp.b0 = o; o += hd;
+  mp.g1 = o; o += hd;
+  mp.be1 = o; o += hd;
+  mp.w3 = o; o += hd * hd;
+  mp.b3 = o; o += hd;
+  mp.g2 = o; o += hd;
+  mp.be2 = o; o += hd;
+  mp.wo = o; o += mp.OD * hd;
+  mp.bo = o; o += mp.OD;
+  return o;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" long long vneti_mapper_num_params(int enc_dim, int hidden, int D, int has_bypass) {
+  MapperParams mp;
+  return fill_mp(mp, enc_dim, hidden, D, has_bypass);
+}
+extern "C" long long vneti_mapper_save_floats(int R, int enc_dim, int hidden) {
+  return (long long)R * (enc_dim + 4 * hidden + 4);
+}
+extern "C" long long vneti_mapper_rowgrad_floats(int R, int hidden, int D, int has_bypass) {
+  return (long long)R * ((has_bypass ? 2 * D : D) + 4 * hidden);
+}
+
+extern "C" int vneti_mapper_fwd(const float* params, const float* data, int nfeat, const float* w_enc,
+                                const float* hidden_mask, float norm_scale, float* word, float* bypass, float* save,
+                                int R, int enc_dim, int hidden, int D, int has_bypass, void* stream) {
+  MapperParams mp;
+  VN_REQUIRE(fill_mp(mp, enc_dim, hidden, D, has_bypass) > 0, "mapper_fwd: unsupported dims E=%d hd=%d D=%d",
+             enc_dim, hidden, D);
+  VN_REQUIRE(params && data && w_enc && word && save && R > 0 && nfeat > 0 && (!has_bypass || bypass),
+             "mapper_fwd: bad arguments");
+  hipLaunchKernelGGL(mapper_fwd_kernel, dim3(R), dim3(256), 0, ST, mp, params, data, nfeat, w_enc, hidden_mask,
+                     norm_scale, word, bypass, save);
+  return vneti_check_launch("mapper_fwd");
+}
+
+extern "C" int vneti_mapper_bwd(const float* params, const float* hidden_mask, float norm_scale, const float* word,
+                                const float* dword_src, const int* dword_rows, long long ld_src,
+                                const float* dbypass, const float* save, float* rowgrads, float* grads,
+                                int accumulate, int R, int enc_dim, int hidden, int D, int has_bypass,
+                                void* stream) {
+  MapperParams mp;
+  int np = fill_mp(mp, enc_dim, hidden, D, has_bypass);
+  VN_REQUIRE(np > 0, "mapper_bwd: unsupported dims E=%d hd=%d D=%d", enc_dim, hidden, D);
+  VN_REQUIRE(params && word && dword_src && dword_rows && save && rowgrads && grads && R > 0,
+             "mapper_bwd: bad arguments");
+  hipLaunchKernelGGL(mapper_bwd_rows_kernel, dim3(R), dim3(256), 0, ST, mp, params, hidden_mask, norm_scale, word,
+                     dword_src, dword_rows, ld_src, dbypass, save, rowgrads);
+  hipLaunchKernelGGL(mapper_bwd_reduce_kernel, dim3(cdiv(np, 256)), dim3(256), 0, ST, mp, R, save,
+                     (const float*)rowgrads, grads, np, accumulate);
+  return vneti_check_launch("mapper_bwd");
+}
+
+extern "C" int vneti_text_embed(const float* tok_emb, const float* pos_emb, const void* ids, const int* pos_obj,
+                                const float* word_obj, const int* pos_view, const float* word_view, float* X, int nl,
+                                int Bn, int L, int D, void* stream) {
+  VN_REQUIRE(tok_emb && pos_emb && ids && X && nl > 0 && Bn > 0 && L > 0 && D % 4 == 0, "text_embed: bad arguments");
+  VN_REQUIRE(!(pos_obj && !word_obj) && !(pos_view && !word_view), "text_embed: placeholder positions without words");
+  long long n = (long long)nl * Bn * L * (D / 4);
+  hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, ST, tok_emb, pos_emb,
+                     (const long long*)ids, pos_obj, word_obj, pos_view, word_view, X, nl, Bn, L, D);
+  return vneti_check_launch("text_embed");
+}
+
+extern "C" int vneti_text_final_fwd(const float* last, const float* gamma, const float* beta, float eps,
+                                    const int* pos_obj, const float* bypass_obj, float alpha_obj,
+                                    const int* pos_view, const float* bypass_view, float alpha_view, void* ctx_k,
+                                    void* ctx_v, int nl, int Bn, int L, int D, void* stream) {
+  VN_REQUIRE(last && gamma && beta && ctx_k && ctx_v && D % 8 == 0 && D <= 8 * 64 * TMAX, "text_final_fwd: bad arguments");
+  BypassArgs o{pos_obj && bypass_obj ? pos_obj : nullptr, bypass_obj, nullptr, alpha_obj};
+  BypassArgs v{pos_view && bypass_view ? pos_view : nullptr, bypass_view, nullptr, alpha_view};
+  long long rows = (long long)nl * Bn * L;
+  hipLaunchKernelGGL(text_final_fwd_kernel, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, ST, last, gamma, beta, eps, o,
+                     v, (half_t*)ctx_k, (half_t*)ctx_v, nl, Bn, L, D);
+  return vneti_check_launch("text_final_fwd");
+}
+
+extern "C" int vneti_text_final_bwd(const float* last, const float* gamma, float eps, const int* pos_obj,
+                                    const float* bypass_obj, float alpha_obj, float* dbypass_obj,
+                                    const int* pos_view, const float* bypass_view, float alpha_view,
+                                    float* dbypass_view, const void* dctx_k, const void* dctx_v, float* dX, int nl,
+                                    int Bn, int L, int D, void* stream) {
+  VN_REQUIRE(last && gamma && dctx_k && dctx_v && dX && D % 8 == 0 && D <= 8 * 64 * TMAX, "text_final_bwd: bad arguments");
+  VN_REQUIRE(!(pos_obj && bypass_obj && !dbypass_obj) && !(pos_view && bypass_view && !dbypass_view),
+             "text_final_bwd: missing bypass gradient buffer");
+  BypassArgs o{pos_obj && bypass_obj ? pos_obj : nullptr, bypass_obj, dbypass_obj, alpha_obj};
+  BypassArgs v{pos_view && bypass_view ? pos_view : nullptr, bypass_view, dbypass_view, alpha_view};
+  long long rows = (long long)nl * Bn * L;
+  hipLaunchKernelGGL(text_final_bwd_kernel, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, ST, last, gamma, eps, o, v,
+                     (const half_t*)dctx_k, (const half_t*)dctx_v, dX, nl, Bn, L, D);
+  return vneti_check_launch("text_final_bwd");
+}
+
+extern "C" int vneti_mapper_inputs(const void* timesteps, const float* view_params, int nv, float* data, int nl,
+                                   int Bn, void* stream) {
+  VN_REQUIRE(timesteps && data && nl > 0 && Bn > 0 && nv >= 0 && (nv == 0 || view_params), "mapper_inputs: bad arguments");
+  int n = nl * Bn * (2 + nv);
+  hipLaunchKernelGGL(mapper_inputs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const long long*)timesteps,
+                     view_params, nv, data, nl, Bn);
+  return vneti_check_launch("mapper_inputs");
+}
+
+extern "C" int vneti_cast_f32_f16(const float* x, void* y, long long n, void* stream) {
+  VN_REQUIRE(x && y && n > 0 && n % 8 == 0, "cast_f32_f16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)cdivl(n / 8, 256)), dim3(256), 0, ST, x, (half_t*)y, n / 8);
+  return vneti_check_launch("cast_f32_f16");
+}

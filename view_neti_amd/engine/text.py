@@ -1,0 +1,264 @@
+"""NeTI text conditioning as one batched HIP launch schedule.
+
+Reference: `Coach.get_text_conditioning` (training/coach.py:276-311) runs the text encoder once per
+UNet cross-attention layer — 16 sequential passes, each with a mapper call, host syncs
+(`.item()`, python `all(...)`) and ~180 tiny kernels.  Here the 16 passes are the batch dimension:
+rows are ordered (layer, sample, token), so every CLIP linear is one M = 16*B*77 GEMM and the
+outputs land directly in the UNet engine's per-layer key/value context buffers.
+
+Numerics follow accelerate's fp16 autocast of the text encoder (training/coach.py:97-99,775-782):
+fp32 embeddings and residual stream, fp16 matmul operands with fp32 accumulation, fp32 LayerNorm
+statistics; the context is rounded to fp16 after the final LayerNorm (coach.py:299-304).
+
+The backward is dgrad-only through CLIP (frozen, coach.py:646-653) down to the placeholder rows of
+the embedding gradient, where the fused mapper backward produces the only weight gradients of the
+whole train step.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+from .. import sd_config as sc
+from .schedule import Schedule, rup
+
+
+class MapperState:
+    """Flat f32 parameter bucket of one NeTIMapper (arch_view_net=15) + its Fourier frequencies."""
+
+    def __init__(self, params: torch.Tensor, w_enc: torch.Tensor, norm_scale: Optional[float], alpha: float,
+                 hidden: int = 64, enc_dim: int = 64):
+        self.params = params
+        self.w_enc = w_enc
+        self.norm_scale = norm_scale
+        self.alpha = alpha
+        self.hidden = hidden
+        self.enc_dim = enc_dim
+
+
+def flatten_mapper_state(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """state_dict (reference key names, checkpoint_handler.py:57-97) -> flat bucket in the order the
+    kernels expect."""
+    keys = ["net.0.weight", "net.0.bias", "net.1.weight", "net.1.bias", "net.3.weight", "net.3.bias",
+            "net.4.weight", "net.4.bias", "output_layer.0.weight", "output_layer.0.bias"]
+    return torch.cat([sd[k].reshape(-1).float() for k in keys])
+
+
+def unflatten_mapper_state(flat: torch.Tensor, enc_dim: int, hidden: int, out_dim: int) -> Dict[str, torch.Tensor]:
+    shapes = [("net.0.weight", (hidden, enc_dim)), ("net.0.bias", (hidden,)), ("net.1.weight", (hidden,)),
+              ("net.1.bias", (hidden,)), ("net.3.weight", (hidden, hidden)), ("net.3.bias", (hidden,)),
+              ("net.4.weight", (hidden,)), ("net.4.bias", (hidden,)), ("output_layer.0.weight", (out_dim, hidden)),
+              ("output_layer.0.bias", (out_dim,))]
+    out, o = {}, 0
+    for k, shp in shapes:
+        n = 1
+        for s in shp:
+            n *= s
+        out[k] = flat[o:o + n].reshape(shp).clone()
+        o += n
+    assert o == flat.numel()
+    return out
+
+
+class TextEngine(Schedule):
+    def __init__(self, cfg: sc.CLIPTextConfig, weights: Dict[str, torch.Tensor], n_layers: int, batch: int,
+                 timesteps: torch.Tensor, ctx_k: torch.Tensor, ctx_v: torch.Tensor, dctx_k: torch.Tensor,
+                 dctx_v: torch.Tensor, mapper_object: MapperState, grads_object: torch.Tensor,
+                 mapper_view: Optional[MapperState] = None, grads_view: Optional[torch.Tensor] = None,
+                 n_view_params: int = 12, train_view: bool = True, device: str = "cuda",
+                 need_backward: bool = True):
+        super().__init__(batch, 32, cfg.eps, device, need_backward)
+        self.cfg = cfg
+        self.nl = n_layers
+        self.L = cfg.max_positions
+        B, L, D, nl = batch, self.L, cfg.hidden_size, n_layers
+        self.R = nl * B
+        self.Rt = nl * B * L
+        self.timesteps = timesteps
+        self.ctx_k, self.ctx_v, self.dctx_k, self.dctx_v = ctx_k, ctx_v, dctx_k, dctx_v
+        assert ctx_k.numel() == self.Rt * D and ctx_k.is_contiguous()
+        self.mo, self.mv = mapper_object, mapper_view
+        self.go, self.gv = grads_object, grads_view
+        self.train_view = train_view and mapper_view is not None
+        # per-batch inputs (static buffers, refreshed by set_batch)
+        self.ids = torch.zeros((B, L), dtype=torch.int64, device=device)
+        self.pos_obj = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.rows_obj = torch.zeros((self.R,), dtype=torch.int32, device=device)
+        self.pos_view = torch.full((B,), -1, dtype=torch.int32, device=device) if mapper_view else None
+        self.rows_view = torch.zeros((self.R,), dtype=torch.int32, device=device) if mapper_view else None
+        self.view_params = self._buf((B, n_view_params), torch.float32, zero=True) if mapper_view else None
+        self.hidden_mask_obj = None  # nested dropout masks may be installed by the trainer
+        self.tok_emb = self._w32(weights["text_model.embeddings.token_embedding.weight"])
+        self.pos_emb = self._w32(weights["text_model.embeddings.position_embedding.weight"])
+        self._build(weights)
+        if need_backward:
+            self._build_backward()
+
+    # ------------------------------------------------------------------ batch plumbing
+    def set_batch(self, input_ids: torch.Tensor, placeholder_object: torch.Tensor,
+                  placeholder_view: Optional[torch.Tensor] = None, view_params: Optional[torch.Tensor] = None):
+        """Host-side equivalent of the `locs = (input_ids == placeholder)` bookkeeping of
+        models/net_clip_text_embedding.py:95-97,127-129 (one placeholder per row, asserted)."""
+        B, L, nl = self.B, self.L, self.nl
+        ids = input_ids.cpu()
+        assert tuple(ids.shape) == (B, L)
+
+        def positions(ph):
+            ph = ph.cpu().view(B, 1)
+            locs = ids == ph
+            if not bool((locs.sum(1) == 1).all()):
+                raise ValueError("each prompt must contain its placeholder token exactly once")
+            return locs.float().argmax(1).to(torch.int32)
+
+        po = positions(placeholder_object)
+        self.ids.copy_(ids)
+        self.pos_obj.copy_(po)
+        base = (torch.arange(nl).view(nl, 1) * B + torch.arange(B).view(1, B)) * L
+        self.rows_obj.copy_((base + po.view(1, B)).reshape(-1).to(torch.int32))
+        if self.mv is not None:
+            if placeholder_view is None or bool((placeholder_view == -1).all()):
+                self.pos_view.fill_(-1)
+            else:
+                pv = positions(placeholder_view)
+                self.pos_view.copy_(pv)
+                self.rows_view.copy_((base + pv.view(1, B)).reshape(-1).to(torch.int32))
+                self.view_params.copy_(view_params.float())
+
+    # ------------------------------------------------------------------ schedule
+    def _mapper_bufs(self, m: MapperState, nfeat):
+        D, R = self.cfg.hidden_size, self.R
+        return dict(data=self._buf((R, nfeat), torch.float32), word=self._buf((R, D), torch.float32),
+                    byp=self._buf((R, D), torch.float32), dbyp=self._buf((R, D), torch.float32, zero=True),
+                    save=self._buf((ops.mapper_save_floats(R, m.enc_dim, m.hidden),), torch.float32),
+                    rowg=self._buf((ops.mapper_rowgrad_floats(R, m.hidden, D),), torch.float32))
+
+    def _build(self, w):
+        cfg = self.cfg
+        B, L, D, nl, R, Rt = self.B, self.L, cfg.hidden_size, self.nl, self.R, self.Rt
+        H = cfg.num_heads
+        hd = D // H
+        F = cfg.intermediate_size
+        f = self.fwd
+        mo = self.mo
+        self.bo = self._mapper_bufs(mo, 2)
+        f.append(partial(ops.mapper_inputs, self.timesteps, None, self.bo["data"], nl, B))
+        f.append(lambda: ops.mapper_fwd(mo.params, self.bo["data"], mo.w_enc, self.hidden_mask_obj, mo.norm_scale,
+                                        self.bo["word"], self.bo["byp"], self.bo["save"], R, mo.enc_dim, mo.hidden, D,
+                                        True))
+        self.bv = None
+        if self.mv is not None:
+            mv = self.mv
+            self.bv = self._mapper_bufs(mv, 2 + self.view_params.shape[1])
+            f.append(partial(ops.mapper_inputs, self.timesteps, self.view_params, self.bv["data"], nl, B))
+            f.append(partial(ops.mapper_fwd, mv.params, self.bv["data"], mv.w_enc, None, mv.norm_scale,
+                             self.bv["word"], self.bv["byp"], self.bv["save"], R, mv.enc_dim, mv.hidden, D, True))
+        x = self._buf((Rt, D), torch.float32)
+        f.append(partial(ops.text_embed, self.tok_emb, self.pos_emb, self.ids, self.pos_obj, self.bo["word"],
+                         self.pos_view, self.bv["word"] if self.bv else None, x, nl, B, L, D))
+        self.x0 = x
+        self.layers = []
+        ldn = rup(L, 8)
+        act = ops.ACT_QUICK_GELU if cfg.act == "quick_gelu" else ops.ACT_GELU
+        for i in range(cfg.num_layers):
+            p = f"text_model.encoder.layers.{i}."
+            r = dict(x_in=x, act=act)
+            n1, r["ln1"] = self._ln(x, p + "layer_norm1", w)
+            wqkv = torch.cat([w[p + "self_attn.q_proj.weight"], w[p + "self_attn.k_proj.weight"],
+                              w[p + "self_attn.v_proj.weight"]], 0)
+            bqkv = torch.cat([w[p + "self_attn.q_proj.bias"], w[p + "self_attn.k_proj.bias"],
+                              w[p + "self_attn.v_proj.bias"]], 0)
+            r["wqkv"], r_bqkv = self._w16(wqkv), self._w32(bqkv)
+            qkv = self._buf((Rt, 3 * D))
+            f.append(partial(ops.gemm, n1, r["wqkv"], qkv, bias=r_bqkv))
+            q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+            vt = self._buf((R, D, ldn))
+            f.append(partial(ops.transpose, v, vt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn))
+            o = self._buf((Rt, D))
+            lse = self._buf((R, H, L), torch.float32)
+            f.append(partial(ops.attn_fwd, q, k, vt, o, lse, R, H, L, L, hd, hd ** -0.5, True, ldn))
+            r["wo"], bo_ = self._w16(w[p + "self_attn.out_proj.weight"]), self._w32(w[p + "self_attn.out_proj.bias"])
+            x_mid = self._buf((Rt, D), torch.float32)
+            f.append(partial(ops.gemm, o, r["wo"], x_mid, bias=bo_, resid=x))
+            n2, r["ln2"] = self._ln(x_mid, p + "layer_norm2", w)
+            r["w1"], b1 = self._w16(w[p + "mlp.fc1.weight"]), self._w32(w[p + "mlp.fc1.bias"])
+            r["w2"], b2 = self._w16(w[p + "mlp.fc2.weight"]), self._w32(w[p + "mlp.fc2.bias"])
+            f1 = self._buf((Rt, F))
+            a1 = self._buf((Rt, F))
+            f.append(partial(ops.gemm, n2, r["w1"], f1, bias=b1))
+            f.append(partial(ops.act_fwd, f1, a1, act))
+            x_out = self._buf((Rt, D), torch.float32)
+            f.append(partial(ops.gemm, a1, r["w2"], x_out, bias=b2, resid=x_mid))
+            r.update(qkv=qkv, o=o, lse=lse, x_mid=x_mid, f1=f1, ldn=ldn)
+            if self.need_backward:
+                tr = lambda t: self._w16(t.t())
+                r["w2d"], r["w1d"] = tr(w[p + "mlp.fc2.weight"]), tr(w[p + "mlp.fc1.weight"])
+                r["wod"], r["wqkvd"] = tr(w[p + "self_attn.out_proj.weight"]), tr(wqkv)
+            self.layers.append(r)
+            x = x_out
+        self.last = x
+        self.fln_g = self._w32(w["text_model.final_layer_norm.weight"])
+        self.fln_b = self._w32(w["text_model.final_layer_norm.bias"])
+        f.append(lambda: ops.text_final_fwd(self.last, self.fln_g, self.fln_b, cfg.eps, self.pos_obj, self.bo["byp"],
+                                            self.mo.alpha, self.pos_view, self.bv["byp"] if self.bv else None,
+                                            self.mv.alpha if self.mv else 0.0, self.ctx_k, self.ctx_v, nl, B, L, D))
+
+    def _build_backward(self):
+        cfg = self.cfg
+        B, L, D, nl, R, Rt = self.B, self.L, cfg.hidden_size, self.nl, self.R, self.Rt
+        H = cfg.num_heads
+        hd = D // H
+        F = cfg.intermediate_size
+        bw = self.bwd
+        dx = self._buf((Rt, D), torch.float32)
+        bw.append(lambda: ops.text_final_bwd(self.last, self.fln_g, cfg.eps, self.pos_obj, self.bo["byp"],
+                                             self.mo.alpha, self.bo["dbyp"], self.pos_view,
+                                             self.bv["byp"] if self.bv else None, self.mv.alpha if self.mv else 0.0,
+                                             self.bv["dbyp"] if self.bv else None, self.dctx_k, self.dctx_v, dx, nl, B,
+                                             L, D))
+        g16 = self._buf((Rt, D))
+        dxm = self._buf((Rt, D), torch.float32)
+        for r in reversed(self.layers):
+            ldn = r["ldn"]
+            qkv = r["qkv"]
+            q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+            bw.append(partial(ops.cast_f32_f16, dx, g16))
+            da = self._tmp("cA", Rt, F)
+            bw.append(partial(ops.gemm, g16, r["w2d"], da))
+            df1 = self._tmp("cB", Rt, F)
+            bw.append(partial(ops.act_bwd, da, r["f1"], df1, r["act"]))
+            dn2 = self._tmp("cC", Rt, D)
+            bw.append(partial(ops.gemm, df1, r["w1d"], dn2))
+            bw.append(partial(self._ln_bwd, r["ln2"], dn2, dxm, dx))          # dx_mid = LN2'(dn2) + dx_out
+            bw.append(partial(ops.cast_f32_f16, dxm, g16))
+            do = self._tmp("cD", Rt, D)
+            bw.append(partial(ops.gemm, g16, r["wod"], do))
+            delta = self._tmp("cdelta", R * H, L, torch.float32)
+            bw.append(partial(ops.attn_bwd_delta, do, r["o"], delta, R, H, L, hd))
+            qt = self._tmp("cQt", R * D, ldn)
+            kt = self._tmp("cKt", R * D, ldn)
+            dot = self._tmp("cdOt", R * D, ldn)
+            bw.append(partial(ops.transpose, q, qt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn))
+            bw.append(partial(ops.transpose, k, kt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn))
+            bw.append(partial(ops.transpose, do, dot, L, D, R, D, L * D, ldn, D * ldn))
+            dqkv = self._tmp("cE", Rt, 3 * D)
+            dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+            sc_ = hd ** -0.5
+            bw.append(partial(ops.attn_bwd_dkv, q, qt, ldn, k, v, do, dot, ldn, r["lse"], delta, dk, dv, R, H, L, L,
+                              hd, sc_, True))
+            bw.append(partial(ops.attn_bwd_dq, q, k, kt, ldn, v, do, r["lse"], delta, dq, R, H, L, L, hd, sc_, True))
+            dn1 = self._tmp("cC", Rt, D)
+            bw.append(partial(ops.gemm, dqkv, r["wqkvd"], dn1))
+            bw.append(partial(self._ln_bwd, r["ln1"], dn1, dx, dxm))          # dx_in = LN1'(dn1) + dx_mid
+        self.dx0 = dx
+        mo = self.mo
+        bw.append(lambda: ops.mapper_bwd(mo.params, self.hidden_mask_obj, mo.norm_scale, self.bo["word"], self.dx0,
+                                         self.rows_obj, D, self.bo["dbyp"], self.bo["save"], self.bo["rowg"], self.go,
+                                         False, R, mo.enc_dim, mo.hidden, D, True))
+        if self.train_view:
+            mv = self.mv
+            bw.append(partial(ops.mapper_bwd, mv.params, None, mv.norm_scale, self.bv["word"], self.dx0,
+                              self.rows_view, D, self.bv["dbyp"], self.bv["save"], self.bv["rowg"], self.gv, False, R,
+                              mv.enc_dim, mv.hidden, D, True))

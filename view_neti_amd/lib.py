@@ -137,4 +137,28 @@ SIGNATURES = {
                          c_vp],
     "mse_loss_grad": [c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "adamw_flat": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_vp],
+    "mapper_fwd": [c_vp, c_vp, c_int, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "mapper_bwd": [c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                   c_int, c_int, c_vp],
+    "text_embed": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "text_final_fwd": [c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp, c_vp, c_int, c_int, c_int,
+                       c_int, c_vp],
+    "text_final_bwd": [c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp, c_int,
+                       c_int, c_int, c_int, c_vp],
+    "cast_f32_f16": [c_vp, c_vp, c_ll, c_vp],
+    "mapper_inputs": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp],
 }
+
+LL_FUNCS = {
+    "mapper_num_params": [c_int] * 4,
+    "mapper_save_floats": [c_int] * 3,
+    "mapper_rowgrad_floats": [c_int] * 4,
+}
+
+
+def call_ll(name: str, *args) -> int:
+    """call a `long long vneti_<name>(...)` size query; negative means unsupported."""
+    fn = getattr(load(), "vneti_" + name)
+    fn.argtypes = LL_FUNCS[name]
+    fn.restype = c_ll
+    return int(fn(*args))

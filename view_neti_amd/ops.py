@@ -191,3 +191,55 @@ def mse_loss_grad(pred, target, dpred, loss_sum, loss_scale, Bn, Lc, HW):
 def adamw_flat(p, g, m, v, hyper, scaler, step, growth_interval=2000):
     _l.call("adamw_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(scaler), _p(step), growth_interval,
             stream())
+
+
+def mapper_num_params(enc_dim, hidden, D, has_bypass=True):
+    return _l.call_ll("mapper_num_params", enc_dim, hidden, D, 1 if has_bypass else 0)
+
+
+def mapper_save_floats(R, enc_dim, hidden):
+    return _l.call_ll("mapper_save_floats", R, enc_dim, hidden)
+
+
+def mapper_rowgrad_floats(R, hidden, D, has_bypass=True):
+    return _l.call_ll("mapper_rowgrad_floats", R, hidden, D, 1 if has_bypass else 0)
+
+
+def mapper_fwd(params, data, w_enc, hidden_mask, norm_scale, word, bypass, save, R, enc_dim, hidden, D, has_bypass):
+    _l.call("mapper_fwd", _p(params), _p(data), data.shape[1], _p(w_enc), _p(hidden_mask),
+            norm_scale if norm_scale is not None else -1.0, _p(word), _p(bypass), _p(save), R, enc_dim, hidden, D,
+            1 if has_bypass else 0, stream())
+
+
+def mapper_bwd(params, hidden_mask, norm_scale, word, dword_src, dword_rows, ld_src, dbypass, save, rowgrads, grads,
+               accumulate, R, enc_dim, hidden, D, has_bypass):
+    _l.call("mapper_bwd", _p(params), _p(hidden_mask), norm_scale if norm_scale is not None else -1.0, _p(word),
+            _p(dword_src), _p(dword_rows), ld_src, _p(dbypass), _p(save), _p(rowgrads), _p(grads),
+            1 if accumulate else 0, R, enc_dim, hidden, D, 1 if has_bypass else 0, stream())
+
+
+def text_embed(tok_emb, pos_emb, ids, pos_obj, word_obj, pos_view, word_view, X, nl, Bn, L, D):
+    _l.call("text_embed", _p(tok_emb), _p(pos_emb), _p(ids), _p(pos_obj), _p(word_obj), _p(pos_view), _p(word_view),
+            _p(X), nl, Bn, L, D, stream())
+
+
+def text_final_fwd(last, gamma, beta, eps, pos_obj, byp_obj, alpha_obj, pos_view, byp_view, alpha_view, ctx_k, ctx_v,
+                   nl, Bn, L, D):
+    _l.call("text_final_fwd", _p(last), _p(gamma), _p(beta), eps, _p(pos_obj), _p(byp_obj), alpha_obj, _p(pos_view),
+            _p(byp_view), alpha_view, _p(ctx_k), _p(ctx_v), nl, Bn, L, D, stream())
+
+
+def text_final_bwd(last, gamma, eps, pos_obj, byp_obj, alpha_obj, dbyp_obj, pos_view, byp_view, alpha_view, dbyp_view,
+                   dctx_k, dctx_v, dX, nl, Bn, L, D):
+    _l.call("text_final_bwd", _p(last), _p(gamma), eps, _p(pos_obj), _p(byp_obj), alpha_obj, _p(dbyp_obj),
+            _p(pos_view), _p(byp_view), alpha_view, _p(dbyp_view), _p(dctx_k), _p(dctx_v), _p(dX), nl, Bn, L, D,
+            stream())
+
+
+def cast_f32_f16(x, y):
+    _l.call("cast_f32_f16", _p(x), _p(y), x.numel(), stream())
+
+
+def mapper_inputs(timesteps, view_params, data, nl, Bn):
+    nv = 0 if view_params is None else view_params.shape[1]
+    _l.call("mapper_inputs", _p(timesteps), _p(view_params), nv, _p(data), nl, Bn, stream())
