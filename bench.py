@@ -1,0 +1,239 @@
+"""Benchmark of the ViewNeTI textual-inversion train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one optimisation step of the reference's Coach.train loop body
+(training/coach.py:154-231) on one micro-batch per GPU: VAE-encode -> sample/add-noise ->
+16 x (NeTI mapper + CLIP text encoder) -> UNet forward with XTI per-layer contexts -> MSE ->
+backward (dgrad through UNet and CLIP, wgrad of the mapper) -> AdamW — nothing cached or skipped.
+Workload = BASELINE.json configs[1]: learnable_mode 0, SD-1.5 shapes, 512x512, fp16, bs=4,
+gradient_accumulation 1, synthetic SD-shaped weights and inputs (no checkpoints / datasets exist
+on the boxes).  Data-parallel weak scaling: every rank runs its own micro-batch, the flat
+mapper-gradient bucket is all-reduced over RCCL; `value` = micro-steps completed by all ranks / s.
+
+Rank 0 prints ONE JSON line with the metric plus
+  "roofline":     measured-with-HIP-events average duration of the dominant kernel family
+                  (the MFMA implicit-GEMM conv/linear kernel) vs the fp16 dense MFMA peak
+  "cpu_baseline": the CPU oracle (oracle/sd_ref.py, a plain-torch fp32 restatement of the same
+                  graph — diffusers itself is not installable here) timed on the host cores on a
+                  bounded sample.  Reported, non-target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # fp16/bf16 dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3: "gemm_kernel<64,64,32,32>",
+              4: "gemm_kernel<256,128,128,64>"}
+# algorithmic FLOPs per sample at 512^2, SD-1.5: VAE 1116.7 + CLIP 16x13.3 + UNet fwd 803.3
+# + UNet dgrad 929.4 + CLIP dgrad 216 GF
+ALGO_GFLOP_PER_SAMPLE_512 = 3278.0
+
+
+def build_engine(args, rank, world):
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.step import TrainStepEngine
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    cfg = sc.CONFIGS[args.model]()
+    dev = "cuda"
+    uw = synth.unet_weights(cfg.unet, device=dev)
+    vw = synth.vae_weights(cfg.vae, device=dev)
+    cw = synth.clip_weights(cfg.clip, device=dev)
+    D = cfg.clip.hidden_size
+    # one placeholder token appended to the vocabulary, initialised from a super-category row and
+    # its norm used as the mapper's norm_scale (training/coach.py:367-395)
+    tok = cw["text_model.embeddings.token_embedding.weight"]
+    super_id = 1125 % cfg.clip.vocab_size
+    cw["text_model.embeddings.token_embedding.weight"] = torch.cat([tok, tok[super_id:super_id + 1]], 0)
+    norm_scale = float(tok[super_id].norm().item())
+    placeholder_id = cfg.clip.vocab_size
+    # reference quirk (App. C Q1): every mapper is initialised right after torch.manual_seed(0)
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    sd = init_mapper_state(64, 64, D)
+    lr = 1e-3 * args.batch * world  # scale_lr rule of training/coach.py:728-733 (accum = 1)
+    eng = TrainStepEngine(cfg, uw, vw, cw, args.batch, args.resolution, args.resolution, sd, w_enc, norm_scale, 0.2,
+                          lr=lr, seed=1234 + rank, world_size=world, device_rng=True)
+    del uw, vw, cw
+    ids = synth.input_ids(args.batch, placeholder_id, cfg.clip.vocab_size)
+    eng.set_batch(synth.pixel_values(args.batch, args.resolution, args.resolution, seed=1 + rank), ids,
+                  torch.full((args.batch,), placeholder_id))
+    return cfg, eng
+
+
+def roofline_pass(eng, reps=3):
+    """Average launch duration of each GEMM tile configuration, measured with HIP events on the
+    launch stream by replaying exactly the step's GEMM launches back to back."""
+    from view_neti_amd import ops
+    groups = {}
+    for f in eng.launches():
+        if getattr(f, "func", None) is not ops.gemm:
+            continue
+        kw = f.keywords
+        A, Bm = f.args[0], f.args[1]
+        M = kw.get("M") or A.shape[-2]
+        N, K = kw.get("N") or Bm.shape[-2], kw.get("K") or Bm.shape[-1]
+        batch = kw.get("batch") or 1
+        tile = kw.get("tile_hint") or ops.gemm_select_tile(M, N, batch)
+        g = groups.setdefault(tile, dict(launches=[], flops=0.0))
+        g["launches"].append(f)
+        g["flops"] += 2.0 * M * N * K * batch
+    out = {}
+    for tile, g in groups.items():
+        for f in g["launches"]:
+            f()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(reps):
+            for f in g["launches"]:
+                f()
+        e.record()
+        torch.cuda.synchronize()
+        total_ms = s.elapsed_time(e) / reps
+        n = len(g["launches"])
+        out[tile] = dict(n=n, total_ms=total_ms, avg_us=total_ms * 1e3 / n, flops_per_launch=g["flops"] / n,
+                         tflops=g["flops"] / (total_ms * 1e-3) / 1e12)
+    return out
+
+
+def cpu_baseline(args):
+    """The oracle's train step on the host cores, on a bounded sample of the same workload
+    (same SD-1.5 weights; bs=1 at a reduced resolution so the default run stays within minutes);
+    converted to the bench unit by the algorithmic-FLOP ratio."""
+    from oracle import sd_ref as R
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = sc.CONFIGS[args.model]()
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    uw = {k: v.cpu() for k, v in synth.unet_weights(cfg.unet, device=dev).items()}
+    vw = {k: v.cpu() for k, v in synth.vae_weights(cfg.vae, device=dev).items()}
+    cw = {k: v.cpu() for k, v in synth.clip_weights(cfg.clip, device=dev).items()}
+    B, res = 1, args.cpu_resolution
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0, preserve_rng=True)
+    sd = {k: v.requires_grad_(True) for k, v in init_mapper_state(64, 64, cfg.clip.hidden_size).items()}
+    ph = cfg.clip.vocab_size - 3
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size)
+    px, t = synth.pixel_values(B, res, res), synth.timesteps(B)
+    eps, noise = synth.gaussian((B, 4, res // 8, res // 8), 3), synth.gaussian((B, 4, res // 8, res // 8), 4)
+    t0 = time.time()
+    loss, _ = R.train_step_loss(cfg, uw, vw, cw, sd, w_enc, 0.4, px, ids, torch.full((B,), ph), t, eps, noise)
+    loss.backward()
+    dt = time.time() - t0
+    # FLOP ratio between the sample and one bench step (VAE and UNet scale with pixels, CLIP with batch)
+    pix = (res / 512.0) ** 2
+    sample_gf = (1116.7 + 803.3 + 929.4) * pix + 212.8 + 216.0
+    bench_gf = ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512.0) ** 2
+    est_steps_per_s = (sample_gf / dt) / bench_gf
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": est_steps_per_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/sd_ref.py fp32 torch-CPU restatement (diffusers not installable), 1 step fwd+bwd at bs=1 "
+                      f"{res}x{res} took {dt:.1f}s ({sample_gf / dt:.1f} GFLOP/s, loss {loss.item():.4f}); scaled to "
+                      f"bs={args.batch} {args.resolution}x{args.resolution} by algorithmic FLOPs; cpu='{model}'"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="sd15")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--resolution", type=int, default=512)
+    ap.add_argument("--cpu-resolution", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    cfg, eng = build_engine(args, rank, world)
+    if not args.no_graph:
+        eng.capture()
+    for _ in range(args.warmup):
+        eng.step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = eng.loss()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.steps / dt
+        rf = roofline_pass(eng)
+        dom = max(rf, key=lambda k: rf[k]["total_ms"])
+        d = rf[dom]
+        out = {
+            "metric": "TI train steps/sec (SD-1.5 512^2 bs=4 per GPU)", "value": value, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"learnable_mode 0, {args.model} shapes, {args.resolution}x{args.resolution} fp16, "
+                                   f"bs={args.batch}/GPU, grad_accum 1, full train step (VAE+16xCLIP+UNet fwd/bwd+AdamW)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "hipgraph": not args.no_graph, "final_loss": loss,
+                       "algorithmic_tflop_per_step": ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512) ** 2 / 1e3,
+                       "end_to_end_mfma_frac": ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512) ** 2 / 1e3
+                                               / (ms * 1e-3) / MFMA_PEAK_TFLOPS,
+                       "engine_gib": eng.memory_bytes() / 2 ** 30},
+            "roofline": {"kernel": TILE_NAMES[dom], "bound": "mfma", "achieved": d["tflops"], "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": d["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": d["n"], "avg_launch_us": d["avg_us"],
+                         "algorithmic_gflop_per_launch": d["flops_per_launch"] / 1e9,
+                         "all_gemm_tiles": {TILE_NAMES[k]: {"launches": v["n"], "ms_per_step": v["total_ms"],
+                                                            "tflops": v["tflops"]} for k, v in rf.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del eng
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

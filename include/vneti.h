@@ -72,6 +72,8 @@ typedef struct vneti_gemm_desc {
 } vneti_gemm_desc;
 
 int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream);
+/* the tile configuration (1..4, see tile_hint) the heuristic picks for a problem size */
+int vneti_gemm_select_tile(int M, int N, int batch);
 
 /* 3x3 im2col for convolutions with tiny Cin (conv_in of UNet / VAE, dgrad of conv_out):
  * out[m][tap*C + c] (f16, row length 64, zero padded) from an arbitrarily strided image.

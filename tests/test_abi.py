@@ -33,5 +33,5 @@ def test_error_convention_no_gpu():
 def test_signatures_cover_header():
     names = set(lib.declared_symbols())
     covered = {"vneti_" + k for k in lib.SIGNATURES} | {"vneti_version", "vneti_last_error", "vneti_gemm_f16",
-                                                       "vneti_groupnorm_ws_floats"} | {"vneti_" + k for k in lib.LL_FUNCS}
+                                                       "vneti_groupnorm_ws_floats"} | {"vneti_" + k for k in lib.LL_FUNCS} | {"vneti_" + k for k in lib.INT_FUNCS}
     assert names <= covered, f"no ctypes signature for {sorted(names - covered)}"

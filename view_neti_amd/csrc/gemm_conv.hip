@@ -350,7 +350,19 @@ int launch_cfg(GemmArgs& g, int batch, bool f32out, hipStream_t st) {
   return vneti_check_launch("gemm_kernel");
 }
 
+// tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
+int select_tile(int M, int N, int batch) {
+  long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
+  long long t12864 = (long long)cdiv(M, 128) * cdiv(N, 64) * batch;
+  if (N <= 64) return (M >= 2048) ? 2 : 3;
+  if (t128 >= 384) return 1;
+  if (t12864 >= 384) return 2;
+  return 3;
+}
+
 }  // namespace
+
+extern "C" int vneti_gemm_select_tile(int M, int N, int batch) { return select_tile(M, N, batch > 0 ? batch : 1); }
 
 extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   VN_REQUIRE(d != nullptr, "gemm: null descriptor");
@@ -419,19 +431,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   VN_REQUIRE(!(f32 && d->rowadd), "gemm: rowadd is only supported for f16 output");
 
   int cfg = d->tile_hint;
-  if (cfg == 0) {
-    // heuristic: fill >= ~2 waves of the 256 CUs when possible, prefer the biggest tile
-    long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch;
-    long long t12864 = (long long)cdiv(d->M, 128) * cdiv(d->N, 64) * batch;
-    if (d->N <= 64)
-      cfg = (d->M >= 2048) ? 2 : 3;
-    else if (t128 >= 384)
-      cfg = 1;
-    else if (t12864 >= 384)
-      cfg = 2;
-    else
-      cfg = 3;
-  }
+  if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 64, 64>(g, batch, f32, st);
     case 2: return launch_cfg<128, 64, 64, 32>(g, batch, f32, st);

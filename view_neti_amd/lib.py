@@ -149,6 +149,8 @@ SIGNATURES = {
     "mapper_inputs": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp],
 }
 
+INT_FUNCS = {"gemm_select_tile": [c_int] * 3}
+
 LL_FUNCS = {
     "mapper_num_params": [c_int] * 4,
     "mapper_save_floats": [c_int] * 3,

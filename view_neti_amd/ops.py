@@ -243,3 +243,9 @@ def cast_f32_f16(x, y):
 def mapper_inputs(timesteps, view_params, data, nl, Bn):
     nv = 0 if view_params is None else view_params.shape[1]
     _l.call("mapper_inputs", _p(timesteps), _p(view_params), nv, _p(data), nl, Bn, stream())
+
+
+def gemm_select_tile(M, N, batch=1):
+    fn = _l.load().vneti_gemm_select_tile
+    fn.argtypes = _l.INT_FUNCS["gemm_select_tile"]
+    return int(fn(M, N, batch))
