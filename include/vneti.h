@@ -68,7 +68,14 @@ typedef struct vneti_gemm_desc {
   int conv_mode;
   int Hi, Wi, Ci, Ho, Wo, stride, pad_t, pad_l, ups;
   long long ldx;
-  int tile_hint;      /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 64x64, 4: 256x128 tiles */
+  int tile_hint;      /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 64x64, 4: 256x128 (8 waves) tiles;
+                         +100 selects the register-staged (non LDS-DMA) reference variant */
+  /* split-K: f32 partials go to `workspace` (>= split_k*batch*M*N*4 bytes) and a second kernel
+     reduces them and applies the epilogue.  split_k 0 = heuristic (only if a workspace is given),
+     1 = off. */
+  void* workspace;
+  long long workspace_bytes;
+  int split_k;
 } vneti_gemm_desc;
 
 int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream);
@@ -147,7 +154,10 @@ int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, long long l
                        const void* dO, long long lddo, const void* dOt, long long lddot,
                        const float* lse, const float* delta, void* dK, long long lddk, void* dV,
                        long long lddv, int Bn, int H, int Nq, int Nk, int D, float scale,
-                       int causal, void* stream);
+                       int causal, float* ws, long long ws_floats, void* stream);
+/* ws (optional f32 scratch): when the key side is short (cross-attention, Nk = 77) the query
+ * range is split across workgroups and the f32 partials are reduced by a second kernel;
+ * needs 2*qsplit*Bn*Nk*H*D floats (qsplit <= 32), NULL disables the split. */
 /* row softmax in place on f16 [rows][ld] (unfused attention of the VAE mid-block, d=512) */
 int vneti_softmax_rows_f16(void* x, long long ld, int rows, int cols, void* stream);
 

@@ -34,7 +34,7 @@ def check(name, got, ref, tol):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 101, 102, 103, 104])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (128, 64, 64), (77 * 4, 1280, 768), (1000, 8, 192)])
 def test_gemm_plain(hint, M, N, K):
     ops = _ops()
@@ -94,13 +94,39 @@ def test_gemm_f32_out_rowadd_act_batch():
     check("gemm batched", outb, Ab.float() @ B.float().t(), 2e-3)
 
 
+@pytest.mark.parametrize("split", [2, 3, 5, 0])
+@pytest.mark.parametrize("f32", [False, True])
+def test_gemm_split_k(split, f32):
+    """split-K partials + reduce kernel must reproduce the fused epilogue (bias, row-add, residual)."""
+    ops = _ops()
+    M, N, K = 200, 328, 64 * 24
+    A = rnd(M, K, seed=41)
+    B = rnd(N, K, scale=1.0 / math.sqrt(K), seed=42)
+    bias = rnd(N, seed=43, dtype=torch.float32)
+    ws = torch.empty(8 * M * N, dtype=torch.float32, device=DEV)
+    if f32:
+        res = rnd(M, N, seed=44, dtype=torch.float32)
+        out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), workspace=ws, split_k=split, tile_hint=3)
+        ref = A.float() @ B.float().t() + bias + res
+    else:
+        res = rnd(M, N, seed=44)
+        radd = rnd(M // 50, N, seed=45)
+        out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+        ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), rowadd=radd.to(DEV), rows_per_group=50,
+                 workspace=ws, split_k=split, tile_hint=3)
+        ref = (A.float() @ B.float().t() + bias).half().float() + radd.float().repeat_interleave(50, 0) + res.float()
+    torch.cuda.synchronize()
+    check(f"gemm split_k={split} f32={f32}", out, ref, 2e-3)
+
+
 # ------------------------------------------------------------------------------------------ conv
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
 @pytest.mark.parametrize("case", ["s1", "s2p1", "s2vae", "ups"])
-@pytest.mark.parametrize("hint", [0, 1, 3])
+@pytest.mark.parametrize("hint", [0, 1, 3, 4, 101, 103])
 def test_conv3x3_fwd(case, hint):
     ops = _ops()
     from view_neti_amd import packing
@@ -262,9 +288,12 @@ def _attn_ref(q, k, v, H, D, scale, causal):
 @pytest.mark.parametrize("D,H,Nq,Nk,causal", [
     (40, 8, 200, 200, False), (40, 2, 300, 77, False), (64, 12, 77, 77, True), (80, 8, 128, 77, False),
     (160, 8, 256, 256, False), (160, 2, 64, 77, False), (64, 3, 200, 200, True), (80, 2, 520, 520, False),
+    (40, 8, 1024, 77, False), (80, 4, 515, 77, False),
 ])
 def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
     ops = _ops()
+    if ops._default_ws is None:  # enables the q-split dK/dV path for short key sides (cross-attention)
+        ops.set_default_gemm_workspace(torch.empty(16 * 2 ** 20, dtype=torch.float32, device=DEV))
     Bn = 2
     Cc = H * D
     scale = D ** -0.5

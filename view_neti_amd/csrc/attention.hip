@@ -42,6 +42,8 @@ struct AttnArgs {
   int Bn, H, Nq, Nk, D;
   float scale;
   int causal;
+  int qsplit;   // dK/dV kernel: number of query ranges per key block (f32 partials -> ws)
+  float* ws;    // [qsplit][2][Bn*Nk][H*D] f32
 };
 
 __device__ __forceinline__ void zero_lds(char* smem, int bytes) {
@@ -457,7 +459,9 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int kb0 = blockIdx.x * 128;
+  const int nkb = cdiv_dev(a.Nk, 128);
+  const int qs = blockIdx.x / nkb;
+  const int kb0 = (blockIdx.x - qs * nkb) * 128;
   const int key = kb0 + wave * 32 + l31;
   const bool kok = key < a.Nk;
 
@@ -560,8 +564,10 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
       dv[i][e] = 0.f;
     }
 
-  const int nqt = cdiv_dev(a.Nq, 32);
-  const int qt0 = a.causal ? min(kb0 / 32, nqt) : 0;
+  const int nqt_all = cdiv_dev(a.Nq, 32);
+  const int per = cdiv_dev(nqt_all, a.qsplit);
+  const int nqt = min(nqt_all, (qs + 1) * per);
+  const int qt0 = max(qs * per, a.causal ? min(kb0 / 32, nqt_all) : 0);
 
   if (qt0 < nqt) issue(qt0);
   for (int qt = qt0; qt < nqt; ++qt) {
@@ -615,6 +621,27 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
     }
   }
 
+  if (a.qsplit > 1) {
+    // f32 partials: ws[qs][0 = dK (unscaled) | 1 = dV][b*Nk + key][h*D + d]
+    if (kok) {
+      const long long plane = (long long)a.Bn * a.Nk * a.H * D;
+      float* kp = a.ws + ((long long)qs * 2) * plane + ((long long)b * a.Nk + key) * (a.H * D) + h * D;
+      float* vp = kp + plane;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          int d = db * 32 + 8 * qd + 4 * h2;
+          if (d < D) {
+            f32x4 k4 = {dk[db][4 * qd], dk[db][4 * qd + 1], dk[db][4 * qd + 2], dk[db][4 * qd + 3]};
+            f32x4 v4 = {dv[db][4 * qd], dv[db][4 * qd + 1], dv[db][4 * qd + 2], dv[db][4 * qd + 3]};
+            *reinterpret_cast<f32x4*>(kp + d) = k4;
+            *reinterpret_cast<f32x4*>(vp + d) = v4;
+          }
+        }
+    }
+    return;
+  }
   if (kok) {
     half_t* krow = a.dK + ((long long)b * a.Nk + key) * a.lddk + h * D;
     half_t* vrow = a.dV + ((long long)b * a.Nk + key) * a.lddv + h * D;
@@ -634,6 +661,27 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
       }
     }
   }
+}
+
+// sum the q-split partials of the dK/dV kernel, apply the softmax scale to dK, round to f16
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs a) {
+  const int Cc = a.H * a.D;
+  const long long rows = (long long)a.Bn * a.Nk;
+  const long long plane = rows * Cc;
+  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= plane / 4) return;
+  const long long e = gid * 4;
+  const long long row = e / Cc;
+  const int c = (int)(e - row * Cc);
+  f32x4 k = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.qsplit; ++s) {
+    k += *reinterpret_cast<const f32x4*>(a.ws + ((long long)s * 2) * plane + e);
+    v += *reinterpret_cast<const f32x4*>(a.ws + ((long long)s * 2 + 1) * plane + e);
+  }
+  half4 k4 = {(half_t)(k[0] * a.scale), (half_t)(k[1] * a.scale), (half_t)(k[2] * a.scale), (half_t)(k[3] * a.scale)};
+  half4 v4 = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  *reinterpret_cast<half4*>(a.dK + row * a.lddk + c) = k4;
+  *reinterpret_cast<half4*>(a.dV + row * a.lddv + c) = v4;
 }
 
 int check_common(int Bn, int H, int Nq, int Nk, int D) {
@@ -735,7 +783,8 @@ extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, 
                                   long long ldk, const void* V, long long ldv, const void* dO, long long lddo,
                                   const void* dOt, long long lddot, const float* lse, const float* delta,
                                   void* dK, long long lddk, void* dV, long long lddv, int Bn, int H, int Nq,
-                                  int Nk, int D, float scale, int causal, void* stream) {
+                                  int Nk, int D, float scale, int causal, float* ws, long long ws_floats,
+                                  void* stream) {
   int rc = check_common(Bn, H, Nq, Nk, D);
   VN_REQUIRE(rc == 0, "attn_bwd_dkv: unsupported shape B=%d H=%d Nq=%d Nk=%d D=%d", Bn, H, Nq, Nk, D);
   VN_REQUIRE(Q && Qt && K && V && dO && dOt && lse && delta && dK && dV, "attn_bwd_dkv: null pointer");
@@ -769,8 +818,26 @@ extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, 
   a.D = D;
   a.scale = scale;
   a.causal = causal;
-  dim3 grid(cdiv(Nk, 128), H, Bn);
+  // few key blocks (cross-attention: Nk = 77) => split the query range so the chip is filled
+  const int nkb = cdiv(Nk, 128), nqt = cdiv(Nq, 32);
+  long long blocks = (long long)nkb * H * Bn;
+  int qsplit = 1;
+  if (ws && !causal && blocks < 256 && nqt >= 8) {
+    qsplit = (int)(512 / blocks);
+    if (qsplit > nqt / 4) qsplit = nqt / 4;
+    if (qsplit > 32) qsplit = 32;
+    const long long plane = (long long)Bn * Nk * H * D;
+    while (qsplit > 1 && 2LL * qsplit * plane > ws_floats) --qsplit;
+    if (qsplit < 2) qsplit = 1;
+  }
+  a.qsplit = qsplit;
+  a.ws = ws;
+  dim3 grid(nkb * qsplit, H, Bn);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_D(attn_dkv_kernel, grid, st, a);
+  if (qsplit > 1) {
+    long long n4 = (long long)Bn * Nk * H * D / 4;
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, st, a);
+  }
   return vneti_check_launch("attn_bwd_dkv");
 }

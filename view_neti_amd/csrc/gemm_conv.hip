@@ -12,12 +12,19 @@
 //     (the to_q/to_k/to_v/to_out calls of models/xti_attention_processor.py:30-55)
 //   - their input-gradient (dgrad) passes: same kernel, pre-transposed weights.
 //
-// Structure (round-1 version): 256-thread workgroup = 4 waves, each wave owns a
-// WM x WN sub-tile built from v_mfma_f32_32x32x16_f16; BK = 64; global -> VGPR
-// (buffer_load_dwordx4, OOB => 0 gives conv zero padding for free) -> LDS
-// (XOR-swizzled, conflict-free ds_read_b128) double buffered with the next
-// tile's global loads in flight under the MFMAs; epilogue staged through LDS so
-// HBM stores are full 16-byte rows with bias / time-embedding / residual fused.
+// Structure: a workgroup of 4 or 8 waves, each wave owning a WM x WN sub-tile built from
+// v_mfma_f32_32x32x16_f16; BK = 64; two LDS stages of [rows][64 halfs] with the 16-byte chunks
+// XOR-swizzled (conflict-free ds_read_b128).  Two ways of filling a stage:
+//   DMA  = true : `buffer_load_dwordx4 ... offen lds` (LDS-DMA): no staging VGPRs, no ds_write
+//                 pass; the swizzle is applied to the per-lane *source* chunk because the LDS
+//                 destination of an LDS-DMA is lane-linear.  Out-of-range offsets return zeros,
+//                 which is how conv zero padding and M/N tails are produced.
+//   DMA  = false: buffer_load to VGPRs + ds_write_b128 (kept as the A/B reference variant).
+// The next tile's loads are in flight under the current tile's MFMAs.  Epilogue staged through
+// LDS so HBM stores are full 16-byte rows with bias / time-embedding row-add / residual fused.
+// Split-K (grid.z) writes f32 partials to a caller workspace; a second kernel reduces them and
+// applies the same epilogue — used for the low-resolution layers whose M is too small to fill
+// 256 CUs (M = 256/1024 with K up to 23040).
 #include "common.h"
 #include "../../include/vneti.h"
 
@@ -30,6 +37,7 @@ struct GemmArgs {
   const float* bias;
   const half_t* rowadd;
   const void* resid;
+  float* ws;
   long long lda, ldb, ldc, ld_rowadd, ldr;
   long long strideA, strideB, strideC;
   uint32_t a_bytes, b_bytes;
@@ -37,10 +45,12 @@ struct GemmArgs {
   int rows_per_group;
   float alpha;
   int act;
+  int out_f32;
+  int batch, ksplit, kt_per_split;
   // implicit conv
   int conv_mode;  // 0 plain, 1 forward gather, 2 transposed gather (dgrad)
   int Hi, Wi, Ci, Ho, Wo, stride, pad_t, pad_l, ups;
-  long long ldx;
+  int ldx2;  // pixel stride in bytes
   int tiles_m, tiles_n;
 };
 
@@ -59,11 +69,22 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int BM, int BN, int WM, int WN, bool F32OUT>
+// one LDS-DMA instruction: 64 lanes x 16 B land at lds_dst + lane*16 (lds_dst wave-uniform).
+// The builtin only exists in the device compilation pass.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, off, 0, 0, 0);
+#else
+  (void)rs; (void)lds_dst; (void)off;
+#endif
+}
+
+template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs g) {
   constexpr int NWM = BM / WM, NWN = BN / WN;
   constexpr int NT = NWM * NWN * 64;
-  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+  constexpr int RSTEP = NT / 8;  // tile rows covered by one pass of all threads
+  constexpr int A_IT = BM / RSTEP, B_IT = BN / RSTEP;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int CS_LD = F32OUT ? (BN + 4) : (BN + 8);  // elements
@@ -73,7 +94,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / NWN) * WM;
   const int wn0 = (wave % NWN) * WN;
 
@@ -89,32 +110,36 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
   const int bz = blockIdx.y;
+  const int kz = blockIdx.z;
 
   const half_t* Ab = g.A + (long long)bz * g.strideA;
   const half_t* Bb = g.B + (long long)bz * g.strideB;
   __amdgpu_buffer_rsrc_t rsA = vn_make_rsrc(Ab, g.a_bytes);
   __amdgpu_buffer_rsrc_t rsB = vn_make_rsrc(Bb, g.b_bytes);
 
-  const int lrow = tid >> 3;  // 0..NT/8-1
-  const int lchk = tid & 7;
+  const int lrow = tid >> 3;  // 0..RSTEP-1
+  // source chunk fetched by this lane: with LDS-DMA the lane's LDS slot is fixed (lane-linear), so
+  // the swizzle moves to the source; with register staging the lane fetches chunk (tid&7) and
+  // writes it to the swizzled slot.  (RSTEP is a multiple of 16 => the swizzle key ignores `i`.)
+  const int gchunk = DMA ? ((tid & 7) ^ ((lrow >> 1) & 7)) : (tid & 7);
 
-  // ---- per-thread A row bookkeeping -------------------------------------------------
-  uint32_t a_base[A_IT];  // plain: byte offset of row start (+chunk); conv: unused
-  int a_py[A_IT], a_px[A_IT], a_pb[A_IT];
+  // ---- per-thread A row bookkeeping (all 32-bit: every tensor is < 2 GiB) -------------------
+  int a_off[A_IT];  // plain: row byte offset; conv: byte offset of the (py, px) corner pixel
+  int a_py[A_IT], a_px[A_IT], a_bh[A_IT];  // conv: corner coords and b*Hi; a_bh < 0 => invalid row
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    int m = m0 + lrow + (NT / 8) * i;
+    int m = m0 + lrow + RSTEP * i;
     bool ok = m < g.M;
     if (g.conv_mode == 0) {
-      a_base[i] = ok ? (uint32_t)((long long)m * g.lda * 2 + lchk * 16) : VN_OOB;
-      a_py[i] = a_px[i] = a_pb[i] = 0;
+      a_off[i] = ok ? (int)((long long)m * g.lda * 2) + gchunk * 16 : -1;
+      a_py[i] = a_px[i] = a_bh[i] = 0;
     } else {
       int hw = g.Ho * g.Wo;
       int b = m / hw;
       int rem = m - b * hw;
       int oy = rem / g.Wo;
       int ox = rem - oy * g.Wo;
-      a_pb[i] = ok ? b : -1;
+      a_bh[i] = ok ? b * g.Hi : -1;
       if (g.conv_mode == 1) {
         a_py[i] = oy * g.stride - g.pad_t;
         a_px[i] = ox * g.stride - g.pad_l;
@@ -122,83 +147,89 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
         a_py[i] = oy + g.pad_t;
         a_px[i] = ox + g.pad_l;
       }
-      a_base[i] = 0;
+      a_off[i] = ((b * g.Hi + a_py[i]) * g.Wi + a_px[i]) * g.ldx2 + gchunk * 16;
     }
   }
-  uint32_t b_base[B_IT];
+  int b_off[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    int n = n0 + lrow + (NT / 8) * i;
-    b_base[i] = (n < g.N) ? (uint32_t)((long long)n * g.ldb * 2 + lchk * 16) : VN_OOB;
+    int n = n0 + lrow + RSTEP * i;
+    b_off[i] = (n < g.N) ? (int)((long long)n * g.ldb * 2) + gchunk * 16 : -1;
   }
 
-  u32x4 ra[A_IT], rb[B_IT];
+  u32x4 ra[DMA ? 1 : A_IT], rb[DMA ? 1 : B_IT];
 
-  auto issue_loads = [&](int kt) {
-    const int k0 = kt * 64;
-    if (g.conv_mode == 0) {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        uint32_t off = (a_base[i] == VN_OOB) ? VN_OOB : a_base[i] + (uint32_t)k0 * 2;
-        ra[i] = vn_buf_load16(rsA, off);
+  // offsets of tile kt for row slot i (VN_OOB => zeros)
+  auto a_offset = [&](int i, int k0, int dy, int dx, int tapoff) -> uint32_t {
+    if (g.conv_mode == 0) return a_off[i] < 0 ? VN_OOB : (uint32_t)(a_off[i] + k0 * 2);
+    bool ok = a_bh[i] >= 0;
+    if (g.conv_mode == 1 && !g.ups) {
+      int iy = a_py[i] + dy, ix = a_px[i] + dx;
+      ok = ok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+      return ok ? (uint32_t)(a_off[i] + tapoff) : VN_OOB;
+    }
+    int iy, ix;
+    if (g.conv_mode == 1) {  // fused nearest-2x upsample
+      iy = a_py[i] + dy;
+      ix = a_px[i] + dx;
+      ok = ok && (unsigned)iy < (unsigned)(2 * g.Hi) && (unsigned)ix < (unsigned)(2 * g.Wi);
+      iy >>= 1;
+      ix >>= 1;
+    } else {  // transposed gather (dgrad)
+      int ty = a_py[i] - dy, tx = a_px[i] - dx;
+      ok = ok && ty >= 0 && tx >= 0;
+      if (g.stride == 2) {
+        ok = ok && ((ty | tx) & 1) == 0;
+        ty >>= 1;
+        tx >>= 1;
       }
-    } else {
+      iy = ty;
+      ix = tx;
+      ok = ok && iy < g.Hi && ix < g.Wi;
+    }
+    return ok ? (uint32_t)(((a_bh[i] + iy) * g.Wi + ix) * g.ldx2 + tapoff) : VN_OOB;
+  };
+
+  auto issue = [&](int kt, int stage) {
+    const int k0 = kt * 64;
+    int dy = 0, dx = 0, tapoff = 0;
+    if (g.conv_mode != 0) {
       const int tap = k0 / g.Ci;
       const int ci0 = k0 - tap * g.Ci;
-      const int dy = tap / 3;
-      const int dx = tap - dy * 3;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        int iy, ix;
-        bool ok = a_pb[i] >= 0;
-        if (g.conv_mode == 1) {
-          iy = a_py[i] + dy;
-          ix = a_px[i] + dx;
-          if (g.ups) {
-            ok = ok && (unsigned)iy < (unsigned)(2 * g.Hi) && (unsigned)ix < (unsigned)(2 * g.Wi);
-            iy >>= 1;
-            ix >>= 1;
-          } else {
-            ok = ok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-          }
-        } else {
-          int ty = a_py[i] - dy;
-          int tx = a_px[i] - dx;
-          ok = ok && ty >= 0 && tx >= 0;
-          if (g.stride == 2) {
-            ok = ok && ((ty | tx) & 1) == 0;
-            ty >>= 1;
-            tx >>= 1;
-          }
-          iy = ty;
-          ix = tx;
-          ok = ok && iy < g.Hi && ix < g.Wi;
-        }
-        uint32_t off = ok ? (uint32_t)((((long long)a_pb[i] * g.Hi + iy) * g.Wi + ix) * g.ldx * 2 +
-                                       (ci0 + lchk * 8) * 2)
-                          : VN_OOB;
-        ra[i] = vn_buf_load16(rsA, off);
-      }
+      dy = tap / 3;
+      dx = tap - dy * 3;
+      // mode 1 (no upsample): offset relative to the corner pixel; otherwise just channel + chunk
+      tapoff = (g.conv_mode == 1 && !g.ups) ? ((dy * g.Wi + dx) * g.ldx2 + ci0 * 2) : (ci0 * 2 + gchunk * 16);
     }
+    if constexpr (DMA) {
+      char* As = smem + stage * STAGE_BYTES;
+      char* Bs = As + BM * 128;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      uint32_t off = (b_base[i] == VN_OOB) ? VN_OOB : b_base[i] + (uint32_t)k0 * 2;
-      rb[i] = vn_buf_load16(rsB, off);
+      for (int i = 0; i < A_IT; ++i) dma16(rsA, As + (wave * 8 + RSTEP * i) * 128, a_offset(i, k0, dy, dx, tapoff));
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i)
+        dma16(rsB, Bs + (wave * 8 + RSTEP * i) * 128, b_off[i] < 0 ? VN_OOB : (uint32_t)(b_off[i] + k0 * 2));
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) ra[i] = vn_buf_load16(rsA, a_offset(i, k0, dy, dx, tapoff));
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        uint32_t off = b_off[i] < 0 ? VN_OOB : (uint32_t)(b_off[i] + k0 * 2);
+        rb[i] = vn_buf_load16(rsB, off);
+      }
     }
   };
 
-  auto store_lds = [&](int buf) {
-    char* As = smem + buf * STAGE_BYTES;
-    char* Bs = As + BM * 128;
+  auto store_lds = [&](int stage) {
+    if constexpr (!DMA) {
+      char* As = smem + stage * STAGE_BYTES;
+      char* Bs = As + BM * 128;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      int r = lrow + (NT / 8) * i;
-      *reinterpret_cast<u32x4*>(As + lds_off(r, lchk)) = ra[i];
-    }
+      for (int i = 0; i < A_IT; ++i)
+        *reinterpret_cast<u32x4*>(As + lds_off(lrow + RSTEP * i, tid & 7)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      int r = lrow + (NT / 8) * i;
-      *reinterpret_cast<u32x4*>(Bs + lds_off(r, lchk)) = rb[i];
+      for (int i = 0; i < B_IT; ++i)
+        *reinterpret_cast<u32x4*>(Bs + lds_off(lrow + RSTEP * i, tid & 7)) = rb[i];
     }
   };
 
@@ -210,32 +241,32 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = g.K / 64;
-  issue_loads(0);
+  const int nk_total = g.K / 64;
+  const int kt_begin = kz * g.kt_per_split;
+  const int kt_end = min(nk_total, kt_begin + g.kt_per_split);
+
+  issue(kt_begin, 0);
   store_lds(0);
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) issue_loads(kt + 1);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
     const char* As = smem + cur * STAGE_BYTES;
     const char* Bs = As + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       half8 af[MI], bf[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        int r = wm0 + i * 32 + frow;
-        af[i] = as_half8(*reinterpret_cast<const u32x4*>(As + lds_off(r, ks * 2 + fhalf)));
-      }
+      for (int i = 0; i < MI; ++i)
+        af[i] = as_half8(*reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, ks * 2 + fhalf)));
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        int r = wn0 + j * 32 + frow;
-        bf[j] = as_half8(*reinterpret_cast<const u32x4*>(Bs + lds_off(r, ks * 2 + fhalf)));
-      }
+      for (int j = 0; j < NI; ++j)
+        bf[j] = as_half8(*reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, ks * 2 + fhalf)));
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -243,8 +274,34 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
           // operands swapped: D[row = n][col = m]  => each lane owns 4 consecutive n of one m
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_lds(cur ^ 1);
+    if (kt + 1 < kt_end) store_lds(cur ^ 1);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+
+  // ---- split-K: raw f32 partials straight to the workspace ---------------------------------
+  if (g.ksplit > 1) {
+    float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int m = m0 + wm0 + i * 32 + frow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn0 + j * 32 + 8 * q + 4 * fhalf;
+          if (m < g.M && n < g.N) {
+            float* p = ws + (long long)m * g.N + n;
+            if (n + 4 <= g.N && (g.N & 3) == 0) {
+              f32x4 o = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              *reinterpret_cast<f32x4*>(p) = o;
+            } else {
+              for (int e = 0; e < 4 && n + e < g.N; ++e) p[e] = acc[i][j][4 * q + e];
+            }
+          }
+        }
+      }
+    return;
   }
 
   // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ---------
@@ -337,27 +394,90 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_cfg(GemmArgs& g, int batch, bool f32out, hipStream_t st) {
+// split-K second pass: C = epi(alpha * sum_z ws[z]) with the same fused epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+  const int n4 = (g.N + 3) / 4;
+  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)g.batch * g.M * n4;
+  if (gid >= total) return;
+  const int c = (int)(gid % n4) * 4;
+  const long long row = gid / n4;
+  const int m = (int)(row % g.M);
+  const int bz = (int)(row / g.M);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ne = min(4, g.N - c);
+  for (int z = 0; z < g.ksplit; ++z) {
+    const float* p = g.ws + ((long long)(z * g.batch + bz) * g.M + m) * g.N + c;
+    if (ne == 4 && (g.N & 3) == 0) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += t[e];
+    } else {
+      for (int e = 0; e < ne; ++e) v[e] += p[e];
+    }
+  }
+  for (int e = 0; e < ne; ++e) {
+    float x = v[e] * g.alpha;
+    if (g.bias) x += g.bias[c + e];
+    x = apply_act(x, g.act);
+    if (g.out_f32) {
+      if (g.resid) x += reinterpret_cast<const float*>(g.resid)[(long long)bz * g.strideC + (long long)m * g.ldr + c + e];
+      reinterpret_cast<float*>(g.C)[(long long)bz * g.strideC + (long long)m * g.ldc + c + e] = x;
+    } else {
+      x = (float)(half_t)x;
+      if (g.rowadd) x = (float)(half_t)(x + (float)g.rowadd[(long long)(m / g.rows_per_group) * g.ld_rowadd + c + e]);
+      if (g.resid)
+        x += (float)reinterpret_cast<const half_t*>(g.resid)[(long long)bz * g.strideC + (long long)m * g.ldr + c + e];
+      reinterpret_cast<half_t*>(g.C)[(long long)bz * g.strideC + (long long)m * g.ldc + c + e] = (half_t)x;
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool DMA>
+int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, BN);
-  dim3 grid(g.tiles_m * g.tiles_n, batch, 1);
+  dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
   dim3 block((BM / WM) * (BN / WN) * 64);
   if (f32out)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA>), grid, block, 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA>), grid, block, 0, st, g);
+  if (g.ksplit > 1) {
+    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
+  }
   return vneti_check_launch("gemm_kernel");
 }
 
+struct TileDims {
+  int bm, bn;
+};
+constexpr TileDims kTiles[5] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 128}};
+
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
+  long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * batch;
   long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * batch;
   long long t12864 = (long long)cdiv(M, 128) * cdiv(N, 64) * batch;
   if (N <= 64) return (M >= 2048) ? 2 : 3;
+  (void)t256;
   if (t128 >= 384) return 1;
   if (t12864 >= 384) return 2;
   return 3;
+}
+
+// split-K factor for a tile choice: only when the grid cannot fill the chip and K is deep
+int select_ksplit(int M, int N, int K, int batch, int tile, long long ws_floats) {
+  if (ws_floats <= 0) return 1;
+  const int nk = K / 64;
+  long long tiles = (long long)cdiv(M, kTiles[tile].bm) * cdiv(N, kTiles[tile].bn) * batch;
+  if (tiles >= 256 || nk < 16) return 1;
+  int s = (int)(512 / tiles);
+  if (s > nk / 8) s = nk / 8;
+  if (s > 16) s = 16;
+  while (s > 1 && (long long)s * batch * M * N > ws_floats) --s;
+  return s < 2 ? 1 : s;
 }
 
 }  // namespace
@@ -390,9 +510,11 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   g.M = d->M;
   g.N = d->N;
   g.K = d->K;
+  g.batch = batch;
   g.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
   g.alpha = d->alpha;
   g.act = d->act;
+  g.out_f32 = d->out_f32 ? 1 : 0;
   g.conv_mode = d->conv_mode;
   long long a_bytes;
   if (d->conv_mode == 0) {
@@ -406,6 +528,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     VN_REQUIRE(d->Ho > 0 && d->Wo > 0 && d->M % (d->Ho * d->Wo) == 0, "conv: M=%d not a multiple of Ho*Wo", d->M);
     VN_REQUIRE(d->ldx % 8 == 0, "conv: ldx must be a multiple of 8");
     VN_REQUIRE(!(d->ups && d->conv_mode != 1), "conv: fused upsample only in forward gather mode");
+    VN_REQUIRE(!(d->ups && d->stride != 1), "conv: fused upsample needs stride 1");
     g.Hi = d->Hi;
     g.Wi = d->Wi;
     g.Ci = d->Ci;
@@ -415,7 +538,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     g.pad_t = d->pad_t;
     g.pad_l = d->pad_l;
     g.ups = d->ups;
-    g.ldx = d->ldx;
+    g.ldx2 = (int)(d->ldx * 2);
     long long nb = d->M / (d->Ho * d->Wo);
     a_bytes = nb * d->Hi * d->Wi * d->ldx * 2;
   }
@@ -431,12 +554,36 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   VN_REQUIRE(!(f32 && d->rowadd), "gemm: rowadd is only supported for f16 output");
 
   int cfg = d->tile_hint;
-  if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
-  switch (cfg) {
-    case 1: return launch_cfg<128, 128, 64, 64>(g, batch, f32, st);
-    case 2: return launch_cfg<128, 64, 64, 32>(g, batch, f32, st);
-    case 3: return launch_cfg<64, 64, 32, 32>(g, batch, f32, st);
-    case 4: return launch_cfg<256, 128, 128, 64>(g, batch, f32, st);
-    default: vneti_set_error("gemm: unknown tile_hint %d", cfg); return VNETI_EARG;
+  bool dma = true;
+  if (cfg >= 100) {  // 10x: register-staged reference variant
+    dma = false;
+    cfg -= 100;
   }
+  if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
+  VN_REQUIRE(cfg >= 1 && cfg <= 4, "gemm: unknown tile_hint %d", d->tile_hint);
+  long long ws_floats = d->workspace ? d->workspace_bytes / 4 : 0;
+  int ks = d->split_k;
+  if (ks == 0) ks = select_ksplit(d->M, d->N, d->K, batch, cfg, ws_floats);
+  if (ks < 1) ks = 1;
+  const int nk = d->K / 64;
+  if (ks > nk) ks = nk;
+  if (ks > 1) {
+    VN_REQUIRE(d->workspace && (long long)ks * batch * d->M * d->N <= ws_floats,
+               "gemm: split_k=%d needs %lld workspace bytes", ks, (long long)ks * batch * d->M * d->N * 4);
+    VN_REQUIRE(batch == 1 || (d->strideC != 0), "gemm: batched split-K needs strideC");
+  }
+  g.ksplit = ks;
+  g.kt_per_split = cdiv(nk, ks);
+  g.ksplit = cdiv(nk, g.kt_per_split);  // drop empty trailing splits
+  g.ws = (float*)d->workspace;
+
+#define LAUNCH(BM, BN, WM, WN) \
+  return dma ? launch_cfg<BM, BN, WM, WN, true>(g, f32, st) : launch_cfg<BM, BN, WM, WN, false>(g, f32, st)
+  switch (cfg) {
+    case 1: LAUNCH(128, 128, 64, 64);
+    case 2: LAUNCH(128, 64, 64, 32);
+    case 3: LAUNCH(64, 64, 32, 32);
+    default: LAUNCH(256, 128, 64, 64);
+  }
+#undef LAUNCH
 }

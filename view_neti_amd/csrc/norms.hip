@@ -120,17 +120,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNGeom g, const half_t* _
   for (int i = threadIdx.x; i < 2 * g.G; i += 256) p[i] = gacc[i];
 }
 
-// one block per sample: reduce the slab partials.  FWD: -> mean, rstd.  BWD: -> (S1/n, S2/n).
+// one block per sample: reduce the slab partials (256 threads: 256/G lanes per group, f64 sums).
+// FWD: -> mean, rstd.  BWD: -> (S1/n, S2/n).
 template <bool BWD>
-__global__ __launch_bounds__(64) void gn_finalize_kernel(GNGeom g, const float* __restrict__ part, float eps,
-                                                         float* __restrict__ o0, float* __restrict__ o1) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GNGeom g, const float* __restrict__ part, float eps,
+                                                          float* __restrict__ o0, float* __restrict__ o1) {
+  __shared__ double red[2][256];
   const int b = blockIdx.x;
-  for (int gi = threadIdx.x; gi < g.G; gi += 64) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < g.nslab; ++s) {
+  const int lpg = 256 / g.G;  // lanes per group (G <= 64 => lpg >= 4)
+  const int gi = threadIdx.x % g.G, ln = threadIdx.x / g.G;
+  double s0 = 0.0, s1 = 0.0;
+  if (ln < lpg) {
+    for (int s = ln; s < g.nslab; s += lpg) {
       const float* p = part + ((long long)b * g.nslab + s) * (2 * g.G) + 2 * gi;
       s0 += (double)p[0];
       s1 += (double)p[1];
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.x < g.G) {
+    s0 = 0.0;
+    s1 = 0.0;
+    for (int l = 0; l < lpg; ++l) {
+      s0 += red[0][l * g.G + gi];
+      s1 += red[1][l * g.G + gi];
     }
     const double n = (double)g.HW * g.cpg;
     if (!BWD) {
@@ -465,7 +480,7 @@ extern "C" int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long l
   dim3 grid(g.nslab, Bn);
   hipLaunchKernelGGL((gn_stats_kernel<false, false>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
                      (const half_t*)nullptr, 0LL, gamma, beta, (const float*)nullptr, (const float*)nullptr, ws);
-  hipLaunchKernelGGL((gn_finalize_kernel<false>), dim3(Bn), dim3(64), 0, st, g, (const float*)ws, eps, mean, rstd);
+  hipLaunchKernelGGL((gn_finalize_kernel<false>), dim3(Bn), dim3(256), 0, st, g, (const float*)ws, eps, mean, rstd);
   if (silu)
     hipLaunchKernelGGL((gn_apply_kernel<false, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
                        (const half_t*)nullptr, 0LL, gamma, beta, (const float*)mean, (const float*)rstd,
@@ -495,7 +510,7 @@ extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x
   else
     hipLaunchKernelGGL((gn_stats_kernel<true, false>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
                        (const half_t*)dy, lddy, gamma, beta, mean, rstd, ws);
-  hipLaunchKernelGGL((gn_finalize_kernel<true>), dim3(Bn), dim3(64), 0, st, g, (const float*)ws, 0.f, c1, c2);
+  hipLaunchKernelGGL((gn_finalize_kernel<true>), dim3(Bn), dim3(256), 0, st, g, (const float*)ws, 0.f, c1, c2);
   if (silu)
     hipLaunchKernelGGL((gn_apply_kernel<true, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
                        (const half_t*)dy, lddy, gamma, beta, mean, rstd, (const float*)c1, (const float*)c2,

@@ -51,6 +51,9 @@ class Schedule:
         self.temb_all = None
         # vneti_groupnorm_ws_floats upper bound: <=256 slabs x 2G partials + 2*B*G finals
         self.gn_ws = self._buf((batch * 256 * 2 * groups + 2 * batch * groups,), torch.float32)
+        # shared f32 scratch for split-K GEMM partials (all schedules run on one stream)
+        if ops._default_ws is None or ops._default_ws.device != torch.device(device, torch.cuda.current_device()):
+            ops.set_default_gemm_workspace(torch.empty(16 * 2 ** 20, dtype=torch.float32, device=device))
 
     # ------------------------------------------------------------------ memory helpers
     def _buf(self, shape, dtype=torch.float16, zero=False):
@@ -96,6 +99,62 @@ class Schedule:
             t.gw = True
             for c in t.children:
                 c.gw = True
+
+    def _contrib_gemm(self, t: T, A, Bm, **kw):
+        """gradient contribution computed by a GEMM (accumulates through the fused residual)."""
+        g = self._grad(t)
+        resid = g if t.gw else None
+        self.bwd.append(partial(ops.gemm, A, Bm, g, resid=resid, **kw))
+        if not t.gw:
+            t.gw = True
+            for c in t.children:
+                c.gw = True
+
+    # ------------------------------------------------------------------ GEMM tile autotuning
+    _tile_cache: Dict[tuple, int] = {}
+
+    @staticmethod
+    def _gemm_key(f):
+        kw = f.keywords
+        A, Bm, out = f.args[:3]
+        conv = kw.get("conv")
+        M = kw.get("M") or A.shape[-2]
+        N = kw.get("N") or Bm.shape[-2]
+        K = kw.get("K") or Bm.shape[-1]
+        ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
+        return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32)
+
+    def autotune(self, candidates=(1, 2, 3, 4), reps=4):
+        """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
+        tile configuration (split-K stays on its heuristic) and pin the fastest.  ~0.3 s per
+        engine; results are cached per problem signature across engines."""
+        if not torch.cuda.is_available():
+            return
+        cache = Schedule._tile_cache
+        for lst in (self.fwd, self.bwd):
+            for idx, f in enumerate(lst):
+                if getattr(f, "func", None) is not ops.gemm or f.keywords.get("tile_hint"):
+                    continue
+                key = self._gemm_key(f)
+                if key not in cache:
+                    best, best_t = 0, float("inf")
+                    for h in candidates:
+                        kw = dict(f.keywords)
+                        kw["tile_hint"] = h
+                        ops.gemm(*f.args, **kw)
+                        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s.record()
+                        for _ in range(reps):
+                            ops.gemm(*f.args, **kw)
+                        e.record()
+                        e.synchronize()
+                        t = s.elapsed_time(e)
+                        if t < best_t:
+                            best, best_t = h, t
+                    cache[key] = best
+                kw = dict(f.keywords)
+                kw["tile_hint"] = cache[key]
+                lst[idx] = partial(ops.gemm, *f.args, **kw)
 
     # ------------------------------------------------------------------ layer builders
     def _gn(self, x: T, name, w, eps, silu):
@@ -173,7 +232,7 @@ class Schedule:
         self.bwd.append(partial(ops.gemm, dh1, r["w1d"], dn1, M=M,
                                 conv=self._conv_desc(h, wd, cout, h, wd, 1, 1, 0, cout, mode=2)))
         if "wscd" in r:
-            self._contrib(x, lambda o, acc, d=dout, wt=r["wscd"]: ops.gemm(d, wt, o, resid=acc))
+            self._contrib_gemm(x, dout, r["wscd"])
             self._contrib(x, self._gn_bwd_fn(r["gn1"], dn1))
         else:
             self._contrib(x, self._gn_bwd_fn(r["gn1"], dn1), extra=dout)
@@ -207,7 +266,7 @@ class Schedule:
         x, out, Cc, h, wd = r["x"], r["out"], r["C"], r["h"], r["wd"]
         assert out.gw
         desc = self._conv_desc(h // 2, wd // 2, Cc, h, wd, 2, r["pad"], 0, out.g.stride(0), mode=2)
-        self._contrib(x, lambda o, acc, d=out.g, wt=r["wd_"]: ops.gemm(d, wt, o, resid=acc, M=x.rows, conv=desc))
+        self._contrib_gemm(x, out.g, r["wd_"], M=x.rows, conv=desc)
 
     # ------------------------------------------------------------------ execution
     def forward(self):

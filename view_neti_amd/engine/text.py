@@ -69,7 +69,7 @@ class TextEngine(Schedule):
                  dctx_v: torch.Tensor, mapper_object: MapperState, grads_object: torch.Tensor,
                  mapper_view: Optional[MapperState] = None, grads_view: Optional[torch.Tensor] = None,
                  n_view_params: int = 12, train_view: bool = True, device: str = "cuda",
-                 need_backward: bool = True):
+                 need_backward: bool = True, autotune: bool = True):
         super().__init__(batch, 32, cfg.eps, device, need_backward)
         self.cfg = cfg
         self.nl = n_layers
@@ -96,6 +96,8 @@ class TextEngine(Schedule):
         self._build(weights)
         if need_backward:
             self._build_backward()
+        if autotune:
+            self.autotune()
 
     # ------------------------------------------------------------------ batch plumbing
     def set_batch(self, input_ids: torch.Tensor, placeholder_object: torch.Tensor,

@@ -30,7 +30,7 @@ from .schedule import Schedule, T, rup as _rup
 
 class UNetEngine(Schedule):
     def __init__(self, cfg: sc.UNetConfig, weights: Dict[str, torch.Tensor], batch: int, height: int, width: int,
-                 ctx_len: int = 77, device: str = "cuda", need_backward: bool = True):
+                 ctx_len: int = 77, device: str = "cuda", need_backward: bool = True, autotune: bool = True):
         super().__init__(batch, cfg.norm_num_groups, cfg.norm_eps, device, need_backward)
         self.cfg = cfg
         self.H, self.W = height, width
@@ -50,6 +50,8 @@ class UNetEngine(Schedule):
         self._build(weights)
         if need_backward:
             self._build_backward()
+        if autotune:
+            self.autotune()
 
     # ------------------------------------------------------------------ time embedding
     def _pack_time_weights(self, w):

@@ -27,7 +27,7 @@ from .schedule import Schedule, T, rup
 
 class VAEEncoderEngine(Schedule):
     def __init__(self, cfg: sc.VAEConfig, weights: Dict[str, torch.Tensor], batch: int, height: int, width: int,
-                 device: str = "cuda"):
+                 device: str = "cuda", autotune: bool = True):
         super().__init__(batch, cfg.norm_num_groups, cfg.norm_eps, device, need_backward=False)
         self.cfg = cfg
         self.H, self.W = height, width
@@ -36,6 +36,8 @@ class VAEEncoderEngine(Schedule):
         self.h_out, self.w_out = height >> (nlev - 1), width >> (nlev - 1)
         self.moments = self._buf((batch * self.h_out * self.w_out, 2 * cfg.latent_channels))
         self._build(weights)
+        if autotune:
+            self.autotune()
 
     def _build(self, w):
         cfg = self.cfg

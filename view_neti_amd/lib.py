@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("stride", c_int), ("pad_t", c_int), ("pad_l", c_int), ("ups", c_int),
         ("ldx", c_ll),
         ("tile_hint", c_int),
+        ("workspace", c_vp), ("workspace_bytes", c_ll), ("split_k", c_int),
     ]
 
 
@@ -121,7 +122,7 @@ SIGNATURES = {
     "attn_bwd_dq": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_ll,
                     c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
     "attn_bwd_dkv": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp,
-                     c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
+                     c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp, c_ll, c_vp],
     "softmax_rows_f16": [c_vp, c_ll, c_int, c_int, c_vp],
     "add_f16": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_vp],
     "geglu_fwd": [c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_vp],

@@ -31,9 +31,18 @@ def _ld(t):
     return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
 
 
+_default_ws = None
+
+
+def set_default_gemm_workspace(t):
+    """f32 scratch used by split-K GEMMs when the caller passes none (single stream only)."""
+    global _default_ws
+    _default_ws = t
+
+
 def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alpha=1.0, act=0,
          tile_hint=0, batch=0, strideA=0, strideB=0, strideC=0, M=None, N=None, K=None, conv=None,
-         lda=None, ldc=None):
+         lda=None, ldc=None, workspace=None, split_k=0):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  `conv` = dict(mode, Hi, Wi, Ci, Ho, Wo, stride,
     pad_t, pad_l, ups, ldx) turns A into an implicit im2col view of an NHWC image."""
     d = _l.GemmDesc()
@@ -64,6 +73,11 @@ def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alp
     d.act = act
     d.out_f32 = 1 if out.dtype == torch.float32 else 0
     d.tile_hint = tile_hint
+    ws = workspace if workspace is not None else _default_ws
+    if ws is not None:
+        d.workspace = ws.data_ptr()
+        d.workspace_bytes = ws.numel() * ws.element_size()
+    d.split_k = split_k if ws is not None else 1
     rc = _l.load().vneti_gemm_f16(C.byref(d), stream())
     _l.check(rc, "gemm_f16")
 
@@ -127,7 +141,7 @@ def attn_bwd_dq(Q, K, Kt, ldkt, V, dO, lse, delta, dQ, Bn, H, Nq, Nk, D, scale, 
 def attn_bwd_dkv(Q, Qt, ldqt, K, V, dO, dOt, lddot, lse, delta, dK, dV, Bn, H, Nq, Nk, D, scale, causal):
     _l.call("attn_bwd_dkv", _p(Q), _ld(Q), _p(Qt), ldqt, _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO),
             _p(dOt), lddot, _p(lse), _p(delta), _p(dK), _ld(dK), _p(dV), _ld(dV), Bn, H, Nq, Nk, D, scale,
-            1 if causal else 0, stream())
+            1 if causal else 0, _p(_default_ws), _default_ws.numel() if _default_ws is not None else 0, stream())
 
 
 def softmax_rows(x, rows, cols):
