@@ -1,0 +1,159 @@
+// GEMM main-loop lab: same structure as view_neti_amd/csrc/gemm_conv.hip (plain NT GEMM only),
+// with ablation macros.  Build: hipcc -DVARIANT_... ; driven by tools/lab/run_lab.py
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef BM
+#define BM 128
+#endif
+#ifndef BN
+#define BN 128
+#endif
+#ifndef WM
+#define WM 64
+#endif
+#ifndef WN
+#define WN 64
+#endif
+#ifndef STAGES
+#define STAGES 2
+#endif
+#define VN_OOB 0x80000000u
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, off, 0, 0, 0);
+#endif
+}
+extern "C" __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void lab_kernel(const half_t* A, const half_t* B,
+                                                                                  half_t* C, int M, int N, int K) {
+  constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64, RSTEP = NT / 8;
+  constexpr int A_IT = BM / RSTEP, B_IT = BN / RSTEP, MI = WM / 32, NI = WN / 32;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  int nblk = tiles_m * tiles_n, bid = blockIdx.x;
+  { int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3; bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((long long)M * K * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((long long)N * K * 2), 0x00020000);
+  const int lrow = tid >> 3;
+  const int gchunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  int a_off[A_IT], b_off[B_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) { int m = m0 + lrow + RSTEP * i; a_off[i] = m < M ? m * K * 2 + gchunk * 16 : -1; }
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) { int n = n0 + lrow + RSTEP * i; b_off[i] = n < N ? n * K * 2 + gchunk * 16 : -1; }
+  auto issue = [&](int kt, int stage) {
+    char* As = smem + stage * STAGE_BYTES; char* Bs = As + BM * 128;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) dma16(rsA, As + (wave * 8 + RSTEP * i) * 128, a_off[i] < 0 ? VN_OOB : (uint32_t)(a_off[i] + kt * 128));
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) dma16(rsB, Bs + (wave * 8 + RSTEP * i) * 128, b_off[i] < 0 ? VN_OOB : (uint32_t)(b_off[i] + kt * 128));
+  };
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int nk = K / 64;
+  const int frow = lane & 31, fhalf = lane >> 5;
+#if STAGES == 2
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+#ifndef NOLOAD
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+#endif
+    const char* As = smem + cur * STAGE_BYTES; const char* Bs = As + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8 af[MI], bf[NI];
+#ifndef NOLDS
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, ks * 2 + fhalf)));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, ks * 2 + fhalf)));
+#else
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { for (int e = 0; e < 8; ++e) af[i][e] = (half_t)(float)(lane + ks + i); }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { for (int e = 0; e < 8; ++e) bf[j][e] = (half_t)(float)(lane - ks + j); }
+#endif
+#ifndef NOMFMA
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+      for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bf[j]));
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#else  // 3 stages: loads run two tiles ahead; counted vmcnt so one tile stays in flight over the barrier
+  constexpr int PER = A_IT + B_IT;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt % 3;
+    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    const char* As = smem + cur * STAGE_BYTES; const char* Bs = As + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, ks * 2 + fhalf)));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, ks * 2 + fhalf)));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    // tile kt+1 must have landed; tile kt+2 may stay in flight
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#endif
+  // minimal epilogue: direct stores (lab only)
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int m = m0 + wm0 + i * 32 + frow;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int n = n0 + wn0 + j * 32 + 8 * q + 4 * fhalf;
+        if (m < M && n + 4 <= N) {
+          half4 o = {(half_t)acc[i][j][4 * q], (half_t)acc[i][j][4 * q + 1], (half_t)acc[i][j][4 * q + 2], (half_t)acc[i][j][4 * q + 3]};
+          *reinterpret_cast<half4*>(C + (long long)m * N + n) = o;
+        }
+      }
+    }
+}
+extern "C" int lab_launch(const void* A, const void* B, void* C, int M, int N, int K, void* stream) {
+  int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  hipLaunchKernelGGL(lab_kernel, dim3(tiles), dim3((BM / WM) * (BN / WN) * 64), 0, (hipStream_t)stream, (const half_t*)A,
+                     (const half_t*)B, (half_t*)C, M, N, K);
+  return (int)hipGetLastError();
+}

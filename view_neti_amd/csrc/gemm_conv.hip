@@ -190,34 +190,54 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     return ok ? (uint32_t)(((a_bh[i] + iy) * g.Wi + ix) * g.ldx2 + tapoff) : VN_OOB;
   };
 
-  auto issue = [&](int kt, int stage) {
+  // Offsets of the tile about to be fetched.  They are recomputed only when the K index crosses
+  // a tap boundary (every Ci/64 tiles, a wave-uniform branch); inside a tap every row just
+  // advances by 128 bytes, so the steady-state address cost equals a plain GEMM's.  An
+  // out-of-range row stays out of range (VN_OOB + a few KiB never wraps).
+  uint32_t a_cur[A_IT], b_cur[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) b_cur[i] = b_off[i] < 0 ? VN_OOB : (uint32_t)b_off[i];
+
+  auto issue = [&](int kt, int stage, bool first) {
     const int k0 = kt * 64;
+    bool recompute = first;
     int dy = 0, dx = 0, tapoff = 0;
     if (g.conv_mode != 0) {
       const int tap = k0 / g.Ci;
       const int ci0 = k0 - tap * g.Ci;
-      dy = tap / 3;
-      dx = tap - dy * 3;
-      // mode 1 (no upsample): offset relative to the corner pixel; otherwise just channel + chunk
-      tapoff = (g.conv_mode == 1 && !g.ups) ? ((dy * g.Wi + dx) * g.ldx2 + ci0 * 2) : (ci0 * 2 + gchunk * 16);
+      recompute = recompute || ci0 == 0;
+      if (recompute) {
+        dy = tap / 3;
+        dx = tap - dy * 3;
+        // mode 1 (no upsample): offset relative to the corner pixel; otherwise just channel + chunk
+        tapoff = (g.conv_mode == 1 && !g.ups) ? ((dy * g.Wi + dx) * g.ldx2 + ci0 * 2) : (ci0 * 2 + gchunk * 16);
+      }
+    }
+    if (recompute) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) a_cur[i] = a_offset(i, k0, dy, dx, tapoff);
+      if (first) {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) b_cur[i] += (uint32_t)k0 * 2;
+      }
     }
     if constexpr (DMA) {
       char* As = smem + stage * STAGE_BYTES;
       char* Bs = As + BM * 128;
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) dma16(rsA, As + (wave * 8 + RSTEP * i) * 128, a_offset(i, k0, dy, dx, tapoff));
+      for (int i = 0; i < A_IT; ++i) dma16(rsA, As + (wave * 8 + RSTEP * i) * 128, a_cur[i]);
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i)
-        dma16(rsB, Bs + (wave * 8 + RSTEP * i) * 128, b_off[i] < 0 ? VN_OOB : (uint32_t)(b_off[i] + k0 * 2));
+      for (int i = 0; i < B_IT; ++i) dma16(rsB, Bs + (wave * 8 + RSTEP * i) * 128, b_cur[i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) ra[i] = vn_buf_load16(rsA, a_offset(i, k0, dy, dx, tapoff));
+      for (int i = 0; i < A_IT; ++i) ra[i] = vn_buf_load16(rsA, a_cur[i]);
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) {
-        uint32_t off = b_off[i] < 0 ? VN_OOB : (uint32_t)(b_off[i] + k0 * 2);
-        rb[i] = vn_buf_load16(rsB, off);
-      }
+      for (int i = 0; i < B_IT; ++i) rb[i] = vn_buf_load16(rsB, b_cur[i]);
     }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) a_cur[i] += 128;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) b_cur[i] += 128;
   };
 
   auto store_lds = [&](int stage) {
@@ -245,7 +265,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   const int kt_begin = kz * g.kt_per_split;
   const int kt_end = min(nk_total, kt_begin + g.kt_per_split);
 
-  issue(kt_begin, 0);
+  issue(kt_begin, 0, true);
   store_lds(0);
   if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -255,7 +275,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
+    if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1, false);
     const char* As = smem + cur * STAGE_BYTES;
     const char* Bs = As + BM * 128;
 #pragma unroll
@@ -450,10 +470,23 @@ int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   return vneti_check_launch("gemm_kernel");
 }
 
+template <int BM, int BN, int WM, int WN, bool DMA>
+int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
+  g.tiles_m = cdiv(g.M, BM);
+  g.tiles_n = cdiv(g.N, BN);
+  dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g);
+  if (g.ksplit > 1) {
+    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
+  }
+  return vneti_check_launch("gemm_kernel");
+}
+
 struct TileDims {
   int bm, bn;
 };
-constexpr TileDims kTiles[5] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 128}};
+constexpr TileDims kTiles[6] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 256}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -560,7 +593,8 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     cfg -= 100;
   }
   if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
-  VN_REQUIRE(cfg >= 1 && cfg <= 4, "gemm: unknown tile_hint %d", d->tile_hint);
+  VN_REQUIRE(cfg >= 1 && cfg <= 5, "gemm: unknown tile_hint %d", d->tile_hint);
+  if (cfg == 5 && f32) cfg = 4;  // the 256x256 tile's f32 epilogue staging would not fit in LDS
   long long ws_floats = d->workspace ? d->workspace_bytes / 4 : 0;
   int ks = d->split_k;
   if (ks == 0) ks = select_ksplit(d->M, d->N, d->K, batch, cfg, ws_floats);
@@ -583,7 +617,9 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     case 1: LAUNCH(128, 128, 64, 64);
     case 2: LAUNCH(128, 64, 64, 32);
     case 3: LAUNCH(64, 64, 32, 32);
-    default: LAUNCH(256, 128, 64, 64);
+    case 4: LAUNCH(256, 128, 64, 64);
+    default:
+      return dma ? launch_cfg_f16<256, 256, 64, 64, true>(g, st) : launch_cfg_f16<256, 256, 64, 64, false>(g, st);
   }
 #undef LAUNCH
 }

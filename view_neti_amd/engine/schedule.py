@@ -124,7 +124,7 @@ class Schedule:
         ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
         return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32)
 
-    def autotune(self, candidates=(1, 2, 3, 4), reps=4):
+    def autotune(self, candidates=(1, 2, 3, 4, 5), reps=4):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
         tile configuration (split-K stays on its heuristic) and pin the fastest.  ~0.3 s per
         engine; results are cached per problem signature across engines."""
