@@ -1,0 +1,73 @@
+"""CPU, world_size 2, gloo: the data-parallel arithmetic of the step — each rank back-propagates its
+own micro-batch, ONE all-reduce(sum) of the flat mapper-gradient bucket, mean folded into AdamW —
+equals single-process training on the concatenated batch (MSE-mean losses of equal-size micro-batches
+average).  Uses the same `parallel.all_reduce_sum_` the GPU engine calls and the oracle for the maths."""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _grads(rank_t, sd, w_enc):
+    from oracle import sd_ref as R
+    from view_neti_amd.engine.text import flatten_mapper_state
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    t = torch.tensor(rank_t, dtype=torch.float32)
+    l = torch.tensor([1.0, 5.0, 9.0, 14.0])
+    word, byp = R.mapper_forward(p, w_enc, t, l, 0.4)
+    tgt = torch.linspace(-1, 1, word.shape[1])
+    loss = ((word - tgt) ** 2).mean() + (byp ** 2).mean()
+    loss.backward()
+    return flatten_mapper_state({k: v.grad for k, v in p.items()}), loss.item()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import sd_ref as R
+    from view_neti_amd import parallel
+    from view_neti_amd.engine.text import flatten_mapper_state
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)  # identical mapper init on every rank
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    sd = init_mapper_state(64, 64, 32)
+    params = flatten_mapper_state(sd)
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    lr = parallel.scaled_lr(1e-3, 1, 4, world)
+    ts = [[10.0, 200.0, 500.0, 900.0], [33.0, 444.0, 555.0, 999.0]][parallel.data_seed(0, rank)]
+    from view_neti_amd.engine.text import unflatten_mapper_state
+    for step in range(1, 4):
+        g, _ = _grads(ts, unflatten_mapper_state(params, 64, 64, 64), w_enc)
+        parallel.all_reduce_sum_(g)
+        params, m, v = R.adamw_step(params, g / world, m, v, step, lr)
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    if rank == 0:
+        torch.save({"params": params, "all": gathered, "lr": lr}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp_two_ranks_equal_single_process(tmp_path):
+    from oracle import sd_ref as R
+    from view_neti_amd.engine.text import flatten_mapper_state, unflatten_mapper_state
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    out = str(tmp_path / "dp.pt")
+    port = 29500 + (os.getpid() % 500)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["all"][0], res["all"][1]), "ranks diverged"
+    assert abs(res["lr"] - 8e-3) < 1e-12  # lr * accum * bs * world (coach.py:728-733)
+    # single process on both micro-batches, mean of the two gradients
+    torch.manual_seed(0)
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    params = flatten_mapper_state(init_mapper_state(64, 64, 32))
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    for step in range(1, 4):
+        sd = unflatten_mapper_state(params, 64, 64, 64)
+        g0, _ = _grads([10.0, 200.0, 500.0, 900.0], sd, w_enc)
+        g1, _ = _grads([33.0, 444.0, 555.0, 999.0], sd, w_enc)
+        params, m, v = R.adamw_step(params, (g0 + g1) / 2, m, v, step, 8e-3)
+    assert torch.allclose(res["params"], params, rtol=1e-5, atol=1e-7)

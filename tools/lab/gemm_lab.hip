@@ -107,15 +107,21 @@ extern "C" __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void lab_ker
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-#else  // 3 stages: loads run two tiles ahead; counted vmcnt so one tile stays in flight over the barrier
+#else  // N-stage ring: loads run STAGES-1 tiles ahead; counted vmcnt, one raw barrier per tile
   constexpr int PER = A_IT + B_IT;
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  constexpr int D = STAGES - 1;
+  for (int t = 0; t < D && t < nk; ++t) issue(t, t % STAGES);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt % 3;
-    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    const int ahead = min(D - 1, nk - 1 - kt);
+    switch (ahead) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + D < nk) issue(kt + D, (kt + D) % STAGES);
+    const int cur = kt % STAGES;
     const char* As = smem + cur * STAGE_BYTES; const char* Bs = As + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -129,10 +135,6 @@ extern "C" __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void lab_ker
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    // tile kt+1 must have landed; tile kt+2 may stay in flight
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
   }
 #endif
   // minimal epilogue: direct stores (lab only)

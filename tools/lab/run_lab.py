@@ -2,17 +2,18 @@
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANTS = {
-    "base_128x128": "",
-    "noload": "-DNOLOAD",
-    "nomfma": "-DNOMFMA",
-    "nolds": "-DNOLDS",
-    "noload_nolds": "-DNOLOAD -DNOLDS",
-    "st3_128x128": "-DSTAGES=3",
-    "base_256x128_8w": "-DBM=256 -DBN=128",
-    "st3_256x128_8w": "-DBM=256 -DBN=128 -DSTAGES=3",
-    "base_256x256_16w": "-DBM=256 -DBN=256",
-    "base_128x256_w64x128": "-DBM=128 -DBN=256 -DWM=64 -DWN=128",
-    "base_256x256_w128x64": "-DBM=256 -DBN=256 -DWM=128 -DWN=64",
+    "64x64_s2": "-DBM=64 -DBN=64 -DWM=32 -DWN=32",
+    "64x64_s3": "-DBM=64 -DBN=64 -DWM=32 -DWN=32 -DSTAGES=3",
+    "64x64_s4": "-DBM=64 -DBN=64 -DWM=32 -DWN=32 -DSTAGES=4",
+    "128x64_s2": "-DBM=128 -DBN=64 -DWM=64 -DWN=32",
+    "128x64_s3": "-DBM=128 -DBN=64 -DWM=64 -DWN=32 -DSTAGES=3",
+    "128x64_s4": "-DBM=128 -DBN=64 -DWM=64 -DWN=32 -DSTAGES=4",
+    "128x128_s2": "",
+    "128x128_s3": "-DSTAGES=3",
+    "128x128_s4": "-DSTAGES=4",
+    "256x128_s2": "-DBM=256 -DBN=128",
+    "256x128_s3": "-DBM=256 -DBN=128 -DSTAGES=3",
+    "256x256_s2": "-DBM=256 -DBN=256",
 }
 def build():
     for name, flags in VARIANTS.items():
@@ -22,7 +23,7 @@ def build():
         print(name, "ok" if r.returncode == 0 else r.stderr[-600:])
 def run():
     import torch
-    shapes = [(4096, 4096, 4096), (16384, 640, 5760), (16384, 320, 2880), (4096, 1280, 11520), (8192, 8192, 8192)]
+    shapes = [(1024, 1280, 1280), (4096, 640, 640), (16384, 320, 320), (4928, 768, 768), (16384, 320, 2880), (4096, 4096, 4096)]
     for name in VARIANTS:
         so = os.path.join(HERE, f"lab_{name}.so")
         if not os.path.exists(so):
@@ -40,7 +41,7 @@ def run():
             for _ in range(10): lib.lab_launch(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, st)
             e.record(); torch.cuda.synchronize()
             t = s.elapsed_time(e) / 10
-            if name.startswith("base") or name.startswith("st3"):
+            if True:
                 ref = (A[:64].float() @ B[:64].float().t()); err = (C[:64, :64].float() - ref).abs().max().item()
                 ok = "" if err < 0.5 else f"!ERR{err:.1f}"
             else:

@@ -9,18 +9,28 @@ import torch
 from view_neti_amd import ops, sd_config as sc, synth
 from view_neti_amd.engine.unet import UNetEngine
 
-cfg = sc.sd15().unet
-B, HW = 4, 64
-w = synth.unet_weights(cfg, device="cuda")
-eng = UNetEngine(cfg, w, B, HW, HW)
-del w
-eng.x_in.copy_(synth.gaussian((B, 4, HW, HW), 5))
-eng.timesteps.copy_(synth.timesteps(B))
-eng.ctx_k.copy_(synth.gaussian(tuple(eng.ctx_k.shape), 6).half())
-eng.ctx_v.copy_(synth.gaussian(tuple(eng.ctx_v.shape), 7).half())
-eng.dpred.copy_(synth.gaussian((B * HW * HW, 4), 8).half() * 0.01)
-eng.forward()
-eng.backward()
+which = os.environ.get("ENGINE", "unet")
+if which == "unet":
+    cfg = sc.sd15().unet
+    B, HW = 4, 64
+    w = synth.unet_weights(cfg, device="cuda")
+    eng = UNetEngine(cfg, w, B, HW, HW, autotune=False)
+    del w
+    eng.x_in.copy_(synth.gaussian((B, 4, HW, HW), 5))
+    eng.timesteps.copy_(synth.timesteps(B))
+    eng.ctx_k.copy_(synth.gaussian(tuple(eng.ctx_k.shape), 6).half())
+    eng.ctx_v.copy_(synth.gaussian(tuple(eng.ctx_v.shape), 7).half())
+    eng.dpred.copy_(synth.gaussian((B * HW * HW, 4), 8).half() * 0.01)
+    eng.forward()
+    eng.backward()
+else:
+    import bench, argparse
+    args = argparse.Namespace(model="sd15", batch=4, resolution=512)
+    import view_neti_amd.engine.schedule as S
+    S.Schedule.autotune = lambda self, *a, **k: None
+    _, step = bench.build_engine(args, 0, 1)
+    step.step_eager()
+    eng = step.vae if which == "vae" else step.text
 torch.cuda.synchronize()
 
 shapes = {}

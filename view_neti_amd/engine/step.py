@@ -144,8 +144,8 @@ class TrainStepEngine:
 
     def all_reduce(self):
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+            from ..parallel import all_reduce_sum_
+            all_reduce_sum_(self.grads)
 
     def step_eager(self):
         self.forward_backward()

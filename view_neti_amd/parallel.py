@@ -1,0 +1,36 @@
+"""Data-parallel pieces of the train step (SURVEY §8e / DESIGN.md §7).
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" on CPU for tests).
+The ONLY exchange of a step is one all-reduce(sum) over the flat fp32 mapper-gradient bucket; the
+mean is folded into the optimizer (`grad_div = world_size`).  The reference would instead wrap the text
+encoder in DDP, which misses the dict-held object mappers and all-reduces the 152 MB embedding table
+(training/coach.py:97-99, models/net_clip_text_embedding.py:25-32) — deliberately not reproduced.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+
+def world_info():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
+    """in-place sum over ranks of the flat gradient bucket (no-op without a process group)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def data_seed(base_seed: int, rank: int) -> int:
+    """rank r draws its own images / noise / timesteps; mapper initialisation uses the SAME seed on
+    every rank (the reference re-seeds with torch.manual_seed(0) inside every mapper constructor)."""
+    return base_seed + rank
+
+
+def scaled_lr(lr: float, grad_accum: int, batch_size: int, world: int, scale_lr: bool = True) -> float:
+    """training/coach.py:728-733: lr * gradient_accumulation_steps * train_batch_size * num_processes"""
+    return lr * grad_accum * batch_size * world if scale_lr else lr
