@@ -1,0 +1,143 @@
+"""CPU tests of the reference-compatible surface: config (+ mini-pyrallis), tokenizer stand-in, dataset
+sample contract, mapper modules and the checkpoint format."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from view_neti_amd.compat import config as C
+from view_neti_amd.compat.checkpoint_handler import CheckpointHandler
+from view_neti_amd.compat.constants import IMAGENET_TEMPLATES_SMALL, UNET_LAYERS
+from view_neti_amd.compat.dataset import TextualInversionDataset
+from view_neti_amd.compat.neti_modules import FourierPositionalEncodingNDims, NeTIMapper
+from view_neti_amd.compat.tokenizer import HashTokenizer
+
+YAML = """
+learnable_mode: 2
+log: {exp_name: t, exp_dir: results, save_steps: 1500}
+data: {train_data_dir: data/x, placeholder_object_token: <object>, dataloader_num_workers: 0,
+       camera_representation: dtu-12d, dtu_subset: 0}
+model: {arch_mlp_hidden_dims: 64, use_nested_dropout: False, word_embedding_dim: 1024, arch_view_net: 15,
+        arch_view_disable_tl: False, pe_sigma_exp_key: 2, output_bypass_alpha_view: 5, output_bypass_alpha_object: 5,
+        pe_sigmas: {sigma_t: 0.5, sigma_l: 9.0, sigma_phi: 2.0, sigma_theta: 2.0}}
+eval: {validation_seeds: [0, 1], num_validation_images: 2}
+optim: {max_train_steps: 10, train_batch_size: 3, gradient_accumulation_steps: 3}
+"""
+
+
+def test_config_defaults_and_post_init(tmp_path):
+    d = C.RunConfig(data=C.DataConfig(train_data_dir="x"))
+    assert d.optim.train_batch_size == 3 and d.optim.gradient_accumulation_steps == 3 and d.optim.mixed_precision == "no"
+    assert d.model.arch_view_net == 0 and d.model.arch_view_disable_tl is True and d.model.word_embedding_dim == 768
+    assert isinstance(d.model.pe_sigmas, C.PESigmas) and d.model.pe_sigmas.sigma_dtu12 == 2.0
+    p = tmp_path / "c.yaml"
+    p.write_text(YAML)
+    cfg = C.parse(C.RunConfig, ["--config_path", str(p), "--optim.learning_rate", "5e-4", "--log.overwrite_ok"])
+    s = cfg.model.pe_sigmas
+    # App. C Q3: sigma_t / sigma_l come from the exp keys (YAML values ignored), phi copied, exp_key 2 -> 0.5
+    assert (s.sigma_t, s.sigma_l, s.sigma_theta, s.sigma_phi, s.sigma_r, s.sigma_dtu12) == (0.03, 2.0, 2.0, 2.0, 2.0, 0.5)
+    assert cfg.optim.learning_rate == 5e-4 and cfg.log.overwrite_ok is True and cfg.log.exp_dir.name == "results"
+    enc = C.encode(cfg)
+    assert isinstance(enc["log"]["exp_dir"], str) and enc["model"]["pe_sigmas"]["sigma_dtu12"] == 0.5
+    assert C.encode(C.decode(C.RunConfig, enc)) == enc  # decode(encode(.)) is the identity on parsed configs
+    with pytest.raises(AssertionError):
+        C.EvalConfig(validation_seeds=[0], num_validation_images=2)
+    with pytest.warns(UserWarning):
+        C.RunConfig(optim=C.OptimConfig(train_batch_size=4))
+
+
+def test_constants():
+    assert len(UNET_LAYERS) == 16 and UNET_LAYERS[6] == "MID" and UNET_LAYERS[-1] == "OUT11"
+    assert len(IMAGENET_TEMPLATES_SMALL) == 27 and all("{}" in t for t in IMAGENET_TEMPLATES_SMALL)
+
+
+def test_tokenizer_contract():
+    tk = HashTokenizer()
+    assert tk.add_tokens(["<view_dtu12d_cam3_1p5_2>", "<obj>"]) == 2 and tk.add_tokens(["<obj>"]) == 0
+    ids = tk("<view_dtu12d_cam3_1p5_2>. A photo of a <obj>").input_ids
+    assert ids.shape == (1, 77) and ids[0, 0] == 49406 and ids[0, -1] == 49407
+    assert (ids[0] == 49408).sum() == 1 and (ids[0] == 49409).sum() == 1 and len(tk) == 49410
+    assert len(tk.encode("object", add_special_tokens=False)) == 1
+
+
+def _make_images(root, names, size=(100, 80)):
+    root.mkdir(parents=True, exist_ok=True)
+    rng = np.random.RandomState(0)
+    for n in names:
+        Image.fromarray(rng.randint(0, 255, (size[1], size[0], 3), dtype=np.uint8)).save(root / n)
+
+
+def test_dataset_mode0(tmp_path):
+    _make_images(tmp_path / "toys", ["a.png", "b.jpg", "c.txt.png"])
+    tk = HashTokenizer()
+    tk.add_tokens(["<toy>"])
+    ds = TextualInversionDataset(tmp_path / "toys", tk, learnable_mode=0, size=64, repeats=5, placeholder_object_token="<toy>")
+    assert len(ds) == 15
+    ex = ds[4]
+    assert ex["pixel_values"].shape == (3, 64, 64) and ex["pixel_values"].dtype == torch.float32
+    assert -1.0 <= ex["pixel_values"].min() and ex["pixel_values"].max() <= 1.0
+    assert ex["input_ids"].shape == (77,) and int(ex["input_ids_placeholder_view"]) == -1
+    assert (ex["input_ids"] == ex["input_ids_placeholder_object"]).sum() == 1 and "<toy>" in ex["text"]
+    with pytest.raises(NotImplementedError):
+        TextualInversionDataset(tmp_path / "toys", tk, augmentation_key=7)
+
+
+def test_dataset_dtu_view_mode(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    cal = tmp_path / "data" / "dtu" / "Calibration" / "cal18"
+    cal.mkdir(parents=True)
+    rng = np.random.RandomState(1)
+    mats = rng.randn(49, 3, 4) * np.array([[1e3, 1e3, 1e3, 1e5]])
+    for i in range(49):
+        np.savetxt(cal / f"pos_{i + 1:03d}.txt", mats[i])
+    scan = tmp_path / "data" / "dtu" / "Rectified" / "scan114"
+    names = [TextualInversionDataset.dtu_cam_and_lighting_to_fname(c, "3") for c in range(49)]
+    _make_images(scan, names + [TextualInversionDataset.dtu_cam_and_lighting_to_fname(0, "1")], size=(160, 120))
+    tk = HashTokenizer()
+    ds = TextualInversionDataset(scan, tk, camera_representation="dtu-12d", learnable_mode=2, dtu_subset=3,
+                                 dtu_lighting=3, dtu_preprocess_key=1, placeholder_object_token="<object>")
+    assert ds.num_images == 3 and len(ds.placeholder_view_tokens) == 3  # DTU_TRAIN_IDX[:3] = 25, 22, 28
+    tk.add_tokens(ds.placeholder_tokens)
+    ex = ds[0]
+    assert ex["pixel_values"].shape == (3, 384, 512)
+    assert ex["text"].startswith("<view_dtu12d_cam22_") and ex["text"].endswith(". A photo of a <object>")
+    # token <-> params round trip is the 4-decimal quantisation of the calibration matrix (App. C Q15)
+    p, key = TextualInversionDataset.dtu_token_to_cam_params(ds.placeholder_view_tokens[0], cam_idx_as_int=True)
+    assert key == 22 and np.allclose(p.numpy(), mats[22].flatten(), atol=6e-5 + 1e-7 * np.abs(mats[22]).max())
+    assert TextualInversionDataset.dtu_get_train_idxs(-3) == list(range(12, 36, 3))
+
+
+def test_mapper_module_and_checkpoint_format(tmp_path):
+    torch.manual_seed(3)
+    m1 = NeTIMapper("object", 768, 64, 0.4, placeholder_object_token="<toy>")
+    m2 = NeTIMapper("object", 768, 64, 0.4, placeholder_object_token="<toy2>")
+    # App. C Q1: every mapper starts identical because the encoder re-seeds the global RNG
+    assert all(torch.equal(a, b) for a, b in zip(m1.mapper_state().values(), m2.mapper_state().values()))
+    assert sum(v.numel() for v in m1.mapper_state().values()) == 108416 and "encoder.w" not in m1.state_dict()
+    assert sum(v.numel() for v in NeTIMapper("object", 1024, 64).mapper_state().values()) == 141696
+    w, b = m1(torch.tensor([10, 500]), torch.tensor([0, 7]))
+    assert w.shape == (2, 768) and torch.allclose(w.norm(dim=-1), torch.full((2,), 0.4), atol=1e-5)
+    cfg = C.RunConfig(data=C.DataConfig(train_data_dir="x", placeholder_object_token="<toy>"),
+                      model=C.ModelConfig(arch_view_net=15, arch_view_disable_tl=False, arch_mlp_hidden_dims=64,
+                                          target_norm_object=0.4, use_nested_dropout=False))
+    h = CheckpointHandler(cfg, [], [], ["<toy>"], [49408], tmp_path)
+    E = torch.randn(49409, 768)
+    h.save_model(E, {49408: m1}, None, "learned_embeds-steps-5.bin", "mapper-steps-5.pt")
+    emb = torch.load(tmp_path / "learned_embeds-steps-5.bin")
+    assert list(emb) == ["<toy>"] and torch.equal(emb["<toy>"], E[49408])
+    ck = torch.load(tmp_path / "mapper-steps-5_object.pt", weights_only=False)
+    assert set(ck) == {"cfg", "mappers"} and list(ck["mappers"]) == [49408]
+    entry = ck["mappers"][49408]
+    assert set(entry) == {"state_dict", "encoder", "placeholder_object_token"} and entry["placeholder_object_token"] == "<toy>"
+    assert list(entry["state_dict"]) == ["net.0.weight", "net.0.bias", "net.1.weight", "net.1.bias", "net.3.weight",
+                                         "net.3.bias", "net.4.weight", "net.4.bias", "output_layer.0.weight",
+                                         "output_layer.0.bias"]
+    assert type(entry["encoder"]).__module__ == "models.positional_encoding"
+    assert type(entry["encoder"]).__name__ == "FourierPositionalEncodingNDims" and ck["cfg"]["model"]["arch_view_net"] == 15
+    cfg2, lookup = CheckpointHandler.load_mapper(tmp_path / "mapper-steps-5_object.pt", "object", ["<toy>"], [49408])
+    assert cfg2.model.target_norm_object == 0.4
+    w2, _ = lookup[49408](torch.tensor([10, 500]), torch.tensor([0, 7]))
+    assert torch.allclose(w, w2)

@@ -1,0 +1,100 @@
+"""Mapper / learned-embedding checkpoints in the reference's on-disk format (checkpoint_handler.py:34-267,
+SURVEY App. D), written from and read into the HIP engine's flat parameter bucket.
+
+  learned_embeds-*.bin      torch.save({token_str: Tensor(D,) cpu fp32}), view tokens first, then object
+  mapper-*_object.pt        {"cfg": encode(RunConfig), "mappers": {token_id: {"state_dict", "encoder",
+                                                                         "placeholder_object_token"}}}
+  mapper-*_view.pt          same with the single key "dummy_key" / token "dummy"
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import config as cfgmod
+from .neti_modules import NeTIMapper
+
+
+class CheckpointHandler:
+    def __init__(self, cfg, placeholder_view_tokens: List[str], placeholder_view_token_ids: List[int],
+                 placeholder_object_tokens: List[str], placeholder_object_token_ids: List[int], save_root: Path):
+        self.cfg = cfg
+        self.placeholder_tokens = list(placeholder_view_tokens) + list(placeholder_object_tokens)
+        self.placeholder_token_ids = list(placeholder_view_token_ids) + list(placeholder_object_token_ids)
+        self.save_root = Path(save_root)
+
+    def save_model(self, token_embedding: torch.Tensor, mapper_object_lookup: Optional[Dict[int, NeTIMapper]],
+                   mapper_view: Optional[NeTIMapper], embeds_save_name: str, mapper_save_name: str):
+        self.save_learned_embeds(token_embedding, embeds_save_name)
+        self.save_mapper(mapper_object_lookup, mapper_view, mapper_save_name)
+
+    def save_learned_embeds(self, token_embedding: torch.Tensor, save_name: str):
+        rows = token_embedding[self.placeholder_token_ids].detach().float().cpu()
+        torch.save({t: v.clone() for t, v in zip(self.placeholder_tokens, rows)}, self.save_root / save_name)
+
+    def save_mapper(self, mapper_object_lookup, mapper_view, save_name: str):
+        enc_cfg = cfgmod.encode(self.cfg)
+        stem, suffix = Path(save_name).stem, Path(save_name).suffix
+        if mapper_object_lookup is not None:
+            sd = {"cfg": enc_cfg, "mappers": {}}
+            for token_id, m in mapper_object_lookup.items():
+                sd["mappers"][token_id] = {"state_dict": m.mapper_state(), "encoder": m.encoder,
+                                           "placeholder_object_token": m.placeholder_object_token}
+            torch.save(sd, os.path.join(self.save_root, stem + "_object" + suffix))
+        if mapper_view is not None:
+            sd = {"cfg": enc_cfg, "mappers": {"dummy_key": {"state_dict": mapper_view.mapper_state(),
+                                                            "encoder": mapper_view.encoder,
+                                                            "placeholder_object_token": "dummy"}}}
+            torch.save(sd, os.path.join(self.save_root, stem + "_view" + suffix))
+
+    @staticmethod
+    def clean_config_dict(d):
+        """drop the None-valued run-time fields that would not decode (checkpoint_handler.py:99-127)."""
+        d["data"].pop("placeholder_view_tokens", None)
+        for sec, keys in (("model", ["target_norm_object", "target_norm_view", "pretrained_view_mapper",
+                                     "pretrained_view_mapper_key"]),
+                          ("eval", ["validation_view_tokens", "eval_placeholder_object_tokens"]),
+                          ("data", ["placeholder_object_tokens", "train_data_subsets"])):
+            for k in keys:
+                if k in d.get(sec, {}) and d[sec][k] is None:
+                    del d[sec][k]
+        return d
+
+    @staticmethod
+    def load_mapper(mapper_path: Path, embedding_type: str = "object", placeholder_object_tokens: List[str] = None,
+                    placeholder_object_token_ids: List[int] = None, cam_mins=None, cam_maxs=None
+                    ) -> Tuple[object, object]:
+        """-> (RunConfig, {token_id: NeTIMapper}) for objects, (RunConfig, NeTIMapper) for the view mapper."""
+        ckpt = torch.load(mapper_path, map_location="cpu", weights_only=False)
+        raw = ckpt["cfg"]
+        cfg = cfgmod.decode(cfgmod.RunConfig, CheckpointHandler.clean_config_dict(dict(raw)))
+        mc = cfg.model
+        is_view = embedding_type == "view"
+        target_norm = mc.target_norm_view if is_view else mc.target_norm_object
+        if not is_view and target_norm is None and mc.normalize_object_mapper_output:
+            raise ValueError("need a target norm to pass to pretrained object mapper")
+        # quirk kept (App. C Q8): the object alpha is read for both mapper kinds
+        alpha = raw["model"].get("output_bypass_alpha_object", 0.2)
+        unconstrained = raw["model"].get("bypass_unconstrained_view" if is_view else "bypass_unconstrained_object", False)
+        out = {}
+        for key, entry in ckpt["mappers"].items():
+            m = NeTIMapper(embedding_type=embedding_type, output_dim=mc.word_embedding_dim,
+                           arch_mlp_hidden_dims=mc.arch_mlp_hidden_dims, norm_scale=target_norm,
+                           pe_sigmas=mc.pe_sigmas, output_bypass=mc.output_bypass_view if is_view else mc.output_bypass_object,
+                           bypass_unconstrained=unconstrained, output_bypass_alpha=alpha,
+                           placeholder_object_token=entry["placeholder_object_token"], cam_mins=cam_mins,
+                           cam_maxs=cam_maxs)
+            state = dict(entry["state_dict"])
+            missing = set(m.mapper_state()) ^ set(state)
+            if missing:
+                raise RuntimeError(f"mapper state_dict keys differ: {sorted(missing)}")
+            m.load_state_dict(state, strict=False)  # strict on the mapper keys (checked above); encoder.w is regenerated
+            m.eval()
+            if is_view:
+                return cfg, m
+            lookup = dict(zip(placeholder_object_tokens, placeholder_object_token_ids))
+            out[lookup[entry["placeholder_object_token"]]] = m
+        return cfg, out

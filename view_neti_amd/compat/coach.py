@@ -1,0 +1,244 @@
+"""Trainer with the surface of the reference's `training/coach.py::Coach` (`Coach(cfg).train()`), driving the
+HIP train-step engine instead of diffusers/transformers/accelerate.
+
+What is mirrored (file:line of the reference):
+  * experiment directory, config.yaml, logs/log.txt                     training/logger.py:19-28
+  * placeholder tokens appended to the tokenizer, their embedding rows initialised from the
+    super-category rows, mapper norm_scale = |E[super]|                 coach.py:320-397
+  * one object mapper per placeholder token (+ view mapper in modes 1-3), all initialised right after the
+    encoder's torch.manual_seed(0) (App. C Q1)                           coach.py:492-598
+  * lr = lr * accum * batch * world when scale_lr                         coach.py:727-733
+  * train loop, save every log.save_steps + final, file names            coach.py:137-274
+What differs on purpose: DESIGN.md §5 (no embedding restore, device RNG, flat-bucket all-reduce);
+validation/inference (`eval.*`) is out of scope for this round.
+"""
+from __future__ import annotations
+
+import logging
+import sys
+import time
+from typing import Dict, Optional
+
+import torch
+
+from .. import parallel
+from .. import sd_config as sc
+from ..engine.step import TrainStepEngine
+from ..engine.text import unflatten_mapper_state
+from . import config as cfgmod
+from .checkpoint_handler import CheckpointHandler
+from .constants import UNET_LAYERS
+from .dataset import TextualInversionDataset
+from .neti_modules import NeTIMapper
+from .sd_weights import load_sd_weights
+from .tokenizer import load_tokenizer
+
+
+def _sd_family(cfg) -> sc.SDConfig:
+    """SD-1.x vs SD-2.x shape family from the word-embedding width (config.py:88-89)."""
+    if cfg.model.word_embedding_dim == 1024:
+        return sc.sd21()
+    if cfg.model.word_embedding_dim == 768:
+        return sc.sd15()
+    if cfg.model.word_embedding_dim == sc.tiny().clip.hidden_size:
+        return sc.tiny()
+    raise ValueError(f"unsupported word_embedding_dim {cfg.model.word_embedding_dim}")
+
+
+class Coach:
+    def __init__(self, cfg: cfgmod.RunConfig, device: str = "cuda"):
+        self.cfg = cfg
+        self.rank, self.world, self.local_rank = parallel.world_info()
+        self.device = device
+        self._setup_logging()
+        if cfg.optim.seed is not None:
+            torch.manual_seed(cfg.optim.seed)
+        if cfg.optim.mixed_precision != "fp16":
+            self.log("NOTE: the HIP engine runs the frozen networks in fp16 (optim.mixed_precision='fp16' "
+                     "semantics) regardless of the configured value")
+        self.sd = _sd_family(cfg)
+        self.tokenizer = load_tokenizer(str(cfg.model.pretrained_model_name_or_path), self.sd.clip.vocab_size)
+        self.train_dataset = self._init_dataset()
+        self._add_concept_tokens()
+        unet_w, vae_w, clip_w, synthetic = load_sd_weights(self.sd, str(cfg.model.pretrained_model_name_or_path), device)
+        if synthetic:
+            self.log(f"NOTE: '{cfg.model.pretrained_model_name_or_path}' is not a local checkpoint directory; using "
+                     "SD-shaped synthetic weights")
+        clip_w = self._extend_token_embedding(clip_w)
+        self.mapper_object_lookup, self.mapper_view = self._init_neti_mappers()
+        first = next(iter(self.mapper_object_lookup.values()))
+        bs = cfg.optim.train_batch_size
+        lr = parallel.scaled_lr(cfg.optim.learning_rate, cfg.optim.gradient_accumulation_steps, bs, self.world,
+                                cfg.optim.scale_lr)
+        h, w = self._image_hw()
+        kw = {}
+        if self.mapper_view is not None:
+            kw = dict(mapper_view=self.mapper_view.mapper_state(), w_enc_view=self.mapper_view.encoder.w,
+                      norm_scale_view=self.mapper_view.norm_scale, alpha_view=cfg.model.output_bypass_alpha_view,
+                      train_view=cfg.learnable_mode != 5)
+        self.engine = TrainStepEngine(
+            self.sd, unet_w, vae_w, clip_w, bs, h, w, first.mapper_state(), first.encoder.w, first.norm_scale,
+            cfg.model.output_bypass_alpha_object, lr=lr, betas=(cfg.optim.adam_beta1, cfg.optim.adam_beta2),
+            adam_eps=cfg.optim.adam_epsilon, weight_decay=cfg.optim.adam_weight_decay,
+            seed=parallel.data_seed(cfg.seed, self.rank), world_size=self.world, device=device,
+            grad_accum=cfg.optim.gradient_accumulation_steps, **kw)
+        del unet_w, vae_w, clip_w
+        self.checkpoint_handler = CheckpointHandler(
+            cfg, self.train_dataset.placeholder_view_tokens, self.placeholder_view_token_ids,
+            self.train_dataset.placeholder_object_tokens, self.placeholder_object_token_ids, cfg.log.exp_dir)
+        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=bs, shuffle=True,
+                                                            num_workers=cfg.data.dataloader_num_workers,
+                                                            drop_last=True)
+
+    # ------------------------------------------------------------------ set-up
+    def _setup_logging(self):
+        cfg = self.cfg
+        self.logger = logging.getLogger(f"vneti.coach.{id(self)}")
+        self.logger.setLevel(logging.INFO)
+        fmt = logging.Formatter("%(asctime)s %(message)s", "%Y-%m-%d %H:%M:%S")
+        if self.rank == 0:
+            cfg.log.exp_dir.mkdir(parents=True, exist_ok=True)
+            cfg.log.logging_dir.mkdir(parents=True, exist_ok=True)
+            for h in (logging.StreamHandler(sys.stdout), logging.FileHandler(cfg.log.logging_dir / "log.txt")):
+                h.setFormatter(fmt)
+                self.logger.addHandler(h)
+            with (cfg.log.exp_dir / "config.yaml").open("w") as f:
+                cfgmod.dump(cfg, f)
+
+    def log(self, msg: str):
+        if self.rank == 0:
+            self.logger.info(msg)
+
+    def _image_hw(self):
+        if "dtu" in str(self.cfg.data.train_data_dir) and self.cfg.learnable_mode != 0:
+            return {0: (512, 512), 1: (384, 512), 2: (576, 768)}[self.cfg.data.dtu_preprocess_key]
+        return self.cfg.data.resolution, self.cfg.data.resolution
+
+    def _init_dataset(self):
+        d = self.cfg.data
+        return TextualInversionDataset(
+            data_root=d.train_data_dir, tokenizer=self.tokenizer, size=d.resolution,
+            placeholder_object_token=d.placeholder_object_token, repeats=d.repeats, center_crop=d.center_crop,
+            set="train", learnable_mode=self.cfg.learnable_mode, camera_representation=d.camera_representation,
+            train_data_subsets=d.train_data_subsets, placeholder_object_tokens=d.placeholder_object_tokens,
+            fixed_object_token_or_path=d.fixed_object_token_or_path, dtu_lighting=d.dtu_lighting,
+            dtu_subset=d.dtu_subset, caption_strategy=d.caption_strategy, dtu_preprocess_key=d.dtu_preprocess_key,
+            augmentation_key=d.augmentation_key)  # flip_p is NOT forwarded — reference quirk Q10
+
+    def _add_concept_tokens(self):
+        ds, tok = self.train_dataset, self.tokenizer
+        self.cfg.data.placeholder_view_tokens = list(ds.placeholder_view_tokens)
+        n = tok.add_tokens(ds.placeholder_view_tokens + ds.placeholder_object_tokens)
+        if n == 0:
+            raise ValueError("No new tokens were added to the tokenizer")
+        self.placeholder_view_token_ids = tok.convert_tokens_to_ids(ds.placeholder_view_tokens) \
+            if ds.placeholder_view_tokens else []
+        self.placeholder_object_token_ids = tok.convert_tokens_to_ids(ds.placeholder_object_tokens)
+        enc = lambda t: tok.encode(t, add_special_tokens=False)
+        so, sv = enc(self.cfg.data.super_category_object_token), enc(self.cfg.data.super_category_view_token)
+        if len(so) != 1 or len(sv) != 1:
+            raise ValueError("super-category tokens must be single vocabulary tokens")
+        self.super_object_id, self.super_view_id = so[0], sv[0]
+
+    def _extend_token_embedding(self, clip_w):
+        key = "text_model.embeddings.token_embedding.weight"
+        E = clip_w[key]
+        extra = len(self.tokenizer) - E.shape[0]
+        rows = torch.empty(extra, E.shape[1], dtype=E.dtype, device=E.device)
+        base = E.shape[0]
+        for i in self.placeholder_view_token_ids:
+            rows[i - base] = E[self.super_view_id]
+        for i in self.placeholder_object_token_ids:
+            rows[i - base] = E[self.super_object_id]
+        clip_w = dict(clip_w)
+        clip_w[key] = torch.cat([E, rows], 0)
+        m = self.cfg.model
+        m.target_norm_view = float(E[self.super_view_id].norm()) if m.normalize_view_mapper_output else None
+        m.target_norm_object = float(E[self.super_object_id].norm()) if m.normalize_object_mapper_output else None
+        self.token_embedding = clip_w[key]
+        return clip_w
+
+    def _init_neti_mappers(self):
+        cfg, m = self.cfg, self.cfg.model
+        if m.arch_view_net != 15 or m.arch_view_disable_tl:
+            raise NotImplementedError("the HIP engine implements the paper's arch_view_net=15 mappers "
+                                      "(set --model.arch_view_net 15 --model.arch_view_disable_tl False)")
+        if m.use_nested_dropout or m.bypass_unconstrained_object or m.bypass_unconstrained_view or m.original_ti:
+            raise NotImplementedError("nested dropout / unconstrained bypass / original_ti are not wired in this round")
+        if len(UNET_LAYERS) != self.sd.unet.n_cross_layers:
+            raise ValueError("UNET_LAYERS does not match the UNet")
+        lookup = {}
+        for token, token_id in zip(self.train_dataset.placeholder_object_tokens, self.placeholder_object_token_ids):
+            lookup[token_id] = NeTIMapper("object", m.word_embedding_dim, m.arch_mlp_hidden_dims, m.target_norm_object,
+                                          m.pe_sigmas, m.output_bypass_object, False, m.output_bypass_alpha_object, token)
+        view = None
+        if cfg.learnable_mode in (1, 2, 3):
+            ds = self.train_dataset
+            cams = torch.stack(list(ds.lookup_camidx_to_cam_params.values()))
+            view = NeTIMapper("view", m.word_embedding_dim, 64, m.target_norm_view, m.pe_sigmas, m.output_bypass_view,
+                              False, m.output_bypass_alpha_view, None, cams.min(0).values.flatten(),
+                              cams.max(0).values.flatten())
+        elif cfg.learnable_mode in (4, 5):
+            ds = self.train_dataset
+            cams = torch.stack(list(ds.lookup_camidx_to_cam_params.values()))
+            _, view = CheckpointHandler.load_mapper(m.pretrained_view_mapper, "view", cam_mins=cams.min(0).values.flatten(),
+                                                    cam_maxs=cams.max(0).values.flatten())
+        if cfg.learnable_mode == 3 or len(lookup) != 1:
+            raise NotImplementedError("multi-object training (learnable_mode 3) needs per-scene mapper switching: next round")
+        return lookup, view
+
+    # ------------------------------------------------------------------ training
+    def _view_params(self, ids_view: torch.Tensor) -> Optional[torch.Tensor]:
+        """camera parameters are parsed back out of the token STRING (4-decimal quantisation, Q15) and scaled
+        to [-1,1] with the min/max over all calibration files (neti_mapper.py:265-337)."""
+        if self.mapper_view is None:
+            return None
+        ds, mv = self.train_dataset, self.mapper_view
+        id2tok = dict(zip(self.placeholder_view_token_ids, ds.placeholder_view_tokens))
+        p = torch.stack([ds.dtu_token_to_cam_params(id2tok[int(i)])[0] for i in ids_view])
+        return (p - mv.cam_mins) / (mv.cam_maxs - mv.cam_mins) * 2 - 1
+
+    def _sync_modules(self):
+        """copy the trained flat bucket back into the nn.Module views used for checkpoints."""
+        eng, D = self.engine, self.cfg.model.word_embedding_dim
+        obj = next(iter(self.mapper_object_lookup.values()))
+        obj.load_state_dict(unflatten_mapper_state(eng.params[: eng.n_obj].cpu(), 64, obj.hidden, 2 * D), strict=False)
+        if self.mapper_view is not None and eng.params.numel() > eng.n_obj:
+            self.mapper_view.load_state_dict(unflatten_mapper_state(eng.params[eng.n_obj:].cpu(), 64, 64, 2 * D),
+                                             strict=False)
+
+    def save(self, embeds_name: str, mapper_name: str):
+        if self.rank != 0:
+            return
+        self._sync_modules()
+        self.checkpoint_handler.save_model(self.token_embedding, self.mapper_object_lookup, self.mapper_view,
+                                           embeds_name, mapper_name)
+
+    def train(self):
+        cfg, eng = self.cfg, self.engine
+        total_bs = cfg.optim.train_batch_size * self.world * cfg.optim.gradient_accumulation_steps
+        for line in ("***** Running training *****", f"  Num examples = {len(self.train_dataset)}",
+                     f"  Instantaneous batch size per device = {cfg.optim.train_batch_size}",
+                     f"  Total train batch size (w. parallel, distributed & accumulation) = {total_bs}",
+                     f"  Gradient Accumulation steps = {cfg.optim.gradient_accumulation_steps}",
+                     f"  Total optimization steps = {cfg.optim.max_train_steps}"):
+            self.log(line)
+        global_step, captured, t0 = 0, False, time.time()
+        while global_step < cfg.optim.max_train_steps:
+            for batch in self.train_dataloader:
+                eng.set_batch(batch["pixel_values"], batch["input_ids"], batch["input_ids_placeholder_object"],
+                              batch["input_ids_placeholder_view"], self._view_params(batch["input_ids_placeholder_view"]))
+                if not captured:
+                    eng.capture()
+                    captured = True
+                if eng.step():
+                    global_step += 1
+                    if global_step % 50 == 0 or global_step == 1:
+                        self.log(f"step {global_step} loss {eng.loss():.5f} lr {float(eng.hyper[0]):.2e} "
+                                 f"{global_step / (time.time() - t0):.2f} it/s")
+                    if global_step % cfg.log.save_steps == 0:
+                        self.save(f"learned_embeds-steps-{global_step}.bin", f"mapper-steps-{global_step}.pt")
+                if global_step >= cfg.optim.max_train_steps:
+                    break
+        torch.cuda.synchronize()
+        self.save("learned_embeds-final.bin", "mapper-final.pt")

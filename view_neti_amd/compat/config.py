@@ -1,0 +1,319 @@
+"""Run configuration with the field names, defaults and `__post_init__` behaviour of the reference's
+`training/config.py:11-293`, plus a small pyrallis-compatible front end (pyrallis is not installed on
+either box): `--config_path file.yaml` + dotted `--a.b value` overrides, `encode`/`decode`/`dump`.
+
+Deliberate deviation: the reference refuses `optim.train_batch_size > 3`
+(config.py:269-271); the headline benchmark is bs=4, so the guard is a warning here.
+"""
+from __future__ import annotations
+
+import dataclasses
+import sys
+import typing
+import warnings
+from dataclasses import dataclass, field, fields, is_dataclass
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Union
+
+import yaml
+
+from .constants import VALIDATION_PROMPTS
+from .pretrained_models import lookup_pretrained_models
+
+
+@dataclass
+class PESigmas:
+    """utils/types.py:17-24 (the reference's `= float` default typo is not reproduced: defaults are None)."""
+    sigma_t: float
+    sigma_l: float
+    sigma_theta: Optional[float] = None
+    sigma_phi: Optional[float] = None
+    sigma_r: Optional[float] = None
+    sigma_dtu12: Optional[float] = None
+
+
+@dataclass
+class LogConfig:
+    exp_name: str = ""
+    overwrite_ok: bool = False
+    exp_dir: Path = Path("./outputs")
+    save_steps: int = 1000
+    logging_dir: Path = Path("logs")
+    report_to: str = "all"
+    checkpoints_total_limit: Optional[int] = None
+    save_dataset_images: bool = True
+
+
+@dataclass
+class DataConfig:
+    train_data_dir: Path = None
+    train_data_subsets: List[Path] = None
+    placeholder_object_token: str = "<>"
+    super_category_object_token: Optional[str] = "object"
+    super_category_view_token: Optional[str] = "view"
+    placeholder_object_tokens: List[str] = None
+    super_category_object_tokens: Optional[List[str]] = None
+    fixed_object_token_or_path: Union[str, Path] = None
+    dataloader_num_workers: int = 8
+    repeats: int = 100
+    resolution: int = 512
+    dtu_preprocess_key: int = 1
+    center_crop: bool = False
+    flip_p: float = 0.5
+    caption_strategy: int = 0
+    camera_representation: str = "spherical"
+    dtu_lighting: str = 3
+    dtu_subset: int = -2
+    augmentation_key: int = 0
+    # filled at run time (a plain class attribute in the reference, config.py:64)
+    placeholder_view_tokens: Optional[List[str]] = None
+
+    def __post_init__(self):
+        # annotated `str` with an int default in the reference (config.py:66); file-name matching needs str
+        self.dtu_lighting = str(self.dtu_lighting)
+
+
+_SIGMA_DTU12 = {1: 1.0, 2: 0.5, 3: 0.25, 4: 0.75, 5: 0.1}
+_SIGMA_T = {0: 0.03, 1: 0.06, 2: 0.2, 3: 0.5}
+_SIGMA_L = {0: 2.0, 1: 4.0}
+
+
+@dataclass
+class ModelConfig:
+    pretrained_model_name_or_path: str = "CompVis/stable-diffusion-v1-4"
+    pretrained_view_mapper: Path = None
+    pretrained_view_mapper_key: int = None
+    word_embedding_dim: int = 768
+    arch_mlp_hidden_dims: int = 128
+    use_nested_dropout: bool = True
+    nested_dropout_prob: float = 0.5
+    normalize_object_mapper_output: bool = True
+    normalize_view_mapper_output: bool = False
+    target_norm_object: float = None
+    target_norm_view: float = None
+    use_positional_encoding_object: int = 1
+    use_positional_encoding_view: int = 1
+    pe_sigmas: Any = field(default_factory=lambda: {"sigma_t": 0.03, "sigma_l": 2.0, "sigma_theta": 1.0,
+                                                    "sigma_phi": 1.0, "sigma_r": 1.0, "sigma_dtu12": 2.0})
+    pe_sigma_exp_key: int = 0
+    pe_t_exp_key: int = 0
+    pe_l_exp_key: int = 0
+    pe_sigmas_view: Dict[str, float] = field(default_factory=lambda: {"sigma_phi": 1.0})
+    num_pe_time_anchors: int = 10
+    output_bypass_object: bool = True
+    output_bypass_view: bool = True
+    revision: Optional[str] = None
+    mapper_checkpoint_path: Optional[Path] = None
+    arch_view_net: int = 0
+    arch_view_mix_streams: int = 0
+    arch_view_disable_tl: bool = True
+    original_ti: bool = False
+    bypass_unconstrained_object: bool = False
+    bypass_unconstrained_view: bool = False
+    output_bypass_alpha_view: float = 0.2
+    output_bypass_alpha_object: float = 0.2
+
+    def __post_init__(self):
+        # config.py:142-178 — the YAML sigma values are overridden by the *_exp_key switches (App. C Q3)
+        if self.pe_sigmas is None:
+            return
+        src = dataclasses.asdict(self.pe_sigmas) if isinstance(self.pe_sigmas, PESigmas) else dict(self.pe_sigmas)
+        phi = src.get("sigma_phi", 1.0)
+        phi = 1.0 if phi is None else phi
+        dtu = src.get("sigma_dtu12", 2.0)
+        sig = PESigmas(sigma_t=src["sigma_t"], sigma_l=src["sigma_l"], sigma_theta=phi, sigma_phi=phi, sigma_r=phi,
+                       sigma_dtu12=2.0 if dtu is None else dtu)
+        if self.pe_sigma_exp_key in _SIGMA_DTU12:
+            sig.sigma_dtu12 = _SIGMA_DTU12[self.pe_sigma_exp_key]
+        if self.pe_t_exp_key not in _SIGMA_T:
+            raise ValueError(f"unknown pe_t_exp_key {self.pe_t_exp_key}")
+        sig.sigma_t = _SIGMA_T[self.pe_t_exp_key]
+        if self.pe_l_exp_key not in _SIGMA_L:
+            raise ValueError(f"unknown pe_l_exp_key {self.pe_l_exp_key}")
+        sig.sigma_l = _SIGMA_L[self.pe_l_exp_key]
+        self.pe_sigmas = sig
+
+
+@dataclass
+class EvalConfig:
+    validation_prompts: List[str] = field(default_factory=lambda: list(VALIDATION_PROMPTS))
+    num_validation_images: int = 3
+    validation_seeds: Optional[List[int]] = field(default_factory=lambda: [0, 1, 2])
+    validation_steps: int = 250
+    num_denoising_steps: int = 30
+    dtu_upsample_key: int = 1
+    eval_placeholder_object_tokens: List[str] = None
+    validation_view_tokens: Optional[List[str]] = None
+
+    def __post_init__(self):
+        if self.validation_seeds is None:
+            self.validation_seeds = list(range(self.num_validation_images))
+        assert len(self.validation_seeds) == self.num_validation_images, \
+            "Length of validation_seeds should equal num_validation_images"
+
+
+@dataclass
+class OptimConfig:
+    max_train_steps: Optional[int] = 1_000
+    learning_rate: float = 1e-3
+    scale_lr: bool = True
+    train_batch_size: int = 3
+    gradient_checkpointing: bool = False
+    gradient_accumulation_steps: int = 3
+    seed: Optional[int] = None
+    lr_scheduler: str = "constant"
+    lr_warmup_steps: int = 0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_weight_decay: float = 1e-2
+    adam_epsilon: float = 1e-08
+    mixed_precision: str = "no"
+    allow_tf32: bool = False
+
+
+@dataclass
+class RunConfig:
+    learnable_mode: int = 0
+    debug: bool = False
+    seed: int = 0
+    log: LogConfig = field(default_factory=LogConfig)
+    data: DataConfig = field(default_factory=DataConfig)
+    model: ModelConfig = field(default_factory=ModelConfig)
+    eval: EvalConfig = field(default_factory=EvalConfig)
+    optim: OptimConfig = field(default_factory=OptimConfig)
+
+    def __post_init__(self):
+        if self.optim.train_batch_size > 3:
+            warnings.warn("reference config.py:269-271 rejects train_batch_size > 3; allowed here (bench uses bs=4)")
+        if self.learnable_mode == 3:
+            assert self.data.dataloader_num_workers == 0, "can't support multiple workers right now for learnable mode 3"
+            assert self.data.super_category_object_tokens is not None
+            if self.eval.eval_placeholder_object_tokens is not None:
+                assert all(d in self.data.placeholder_object_tokens for d in self.eval.eval_placeholder_object_tokens), \
+                    "eval.eval_placeholder_tokens not in data.placeholder_object_tokens"
+        if self.data.placeholder_object_tokens is not None:
+            assert len(self.data.placeholder_object_tokens) == len(set(self.data.placeholder_object_tokens)), \
+                "cfg.data.placeholder_object_tokens must be unique strings"
+        if self.learnable_mode in (4, 5):
+            assert self.model.pretrained_view_mapper or self.model.pretrained_view_mapper_key
+            if self.model.pretrained_view_mapper_key:
+                self.model.pretrained_view_mapper = lookup_pretrained_models[str(self.model.pretrained_view_mapper_key)]
+
+
+# ----------------------------------------------------------------------------------------------
+# mini-pyrallis
+# ----------------------------------------------------------------------------------------------
+def encode(obj):
+    """pyrallis.encode: dataclass -> plain dict (Path -> str), used for config.yaml and inside checkpoints
+    (training/logger.py:25-28, checkpoint_handler.py:59,64)."""
+    if is_dataclass(obj) and not isinstance(obj, type):
+        return {f.name: encode(getattr(obj, f.name)) for f in fields(obj)}
+    if isinstance(obj, Path):
+        return str(obj)
+    if isinstance(obj, dict):
+        return {k: encode(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [encode(v) for v in obj]
+    return obj
+
+
+def _coerce(tp, val):
+    if val is None:
+        return None
+    origin = typing.get_origin(tp)
+    if origin is Union:
+        args = [a for a in typing.get_args(tp) if a is not type(None)]
+        for a in args:
+            try:
+                return _coerce(a, val)
+            except (TypeError, ValueError):
+                continue
+        return val
+    if origin in (list, List):
+        (a,) = typing.get_args(tp) or (Any,)
+        if isinstance(val, str):
+            val = yaml.safe_load(val)
+        return [_coerce(a, v) for v in val]
+    if origin in (dict, Dict):
+        return yaml.safe_load(val) if isinstance(val, str) else dict(val)
+    if tp is Path:
+        return Path(val)
+    if tp is bool:
+        return val if isinstance(val, bool) else str(val).lower() in ("1", "true", "yes")
+    if tp in (int, float, str):
+        return tp(val)
+    if isinstance(tp, type) and is_dataclass(tp):
+        return decode(tp, val)
+    if isinstance(val, str) and tp is Any:
+        try:
+            return yaml.safe_load(val)
+        except yaml.YAMLError:
+            return val
+    return val
+
+
+def decode(cls, d: Dict[str, Any]):
+    """pyrallis.decode: plain dict -> dataclass (checkpoint_handler.py:142)."""
+    hints = typing.get_type_hints(cls)
+    kwargs = {}
+    for f in fields(cls):
+        if f.name in d:
+            kwargs[f.name] = _coerce(hints[f.name], d[f.name])
+    return cls(**kwargs)
+
+
+def dump(cfg, stream=None) -> Optional[str]:
+    text = yaml.safe_dump(encode(cfg), sort_keys=False)
+    if stream is None:
+        return text
+    stream.write(text)
+    return None
+
+
+def _set_dotted(d: Dict[str, Any], key: str, value):
+    parts = key.split(".")
+    for p in parts[:-1]:
+        d = d.setdefault(p, {})
+    d[parts[-1]] = value
+
+
+def parse(cls=RunConfig, args: Optional[List[str]] = None):
+    """`--config_path file.yaml` first, then dotted overrides `--optim.train_batch_size 4`
+    (README.md:40-44 of the reference); a bare flag such as `--log.overwrite_ok` means True."""
+    args = list(sys.argv[1:] if args is None else args)
+    d: Dict[str, Any] = {}
+    overrides = []
+    i = 0
+    while i < len(args):
+        a = args[i]
+        if not a.startswith("--"):
+            raise SystemExit(f"unexpected argument {a!r}")
+        key = a[2:]
+        if "=" in key:
+            key, val = key.split("=", 1)
+            i += 1
+        elif i + 1 < len(args) and not args[i + 1].startswith("--"):
+            val = args[i + 1]
+            i += 2
+        else:
+            val = True
+            i += 1
+        if key == "config_path":
+            with open(val) as f:
+                d = yaml.safe_load(f) or {}
+        else:
+            overrides.append((key, val))
+    for key, val in overrides:
+        _set_dotted(d, key, val)
+    return decode(cls, d)
+
+
+def wrap():
+    """decorator with pyrallis.wrap()'s calling convention (scripts/train.py:19)."""
+    def deco(fn):
+        def inner(*a, **k):
+            hints = typing.get_type_hints(fn)
+            cls = next(iter(hints.values()))
+            return fn(parse(cls), *a, **k)
+        return inner
+    return deco

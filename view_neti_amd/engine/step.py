@@ -46,7 +46,7 @@ class TrainStepEngine:
                  n_view_params: int = 12, lr: float = 1e-3, betas=(0.9, 0.999), adam_eps: float = 1e-8,
                  weight_decay: float = 1e-2, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  seed: int = 0, world_size: int = 1, device_rng: bool = True, device: str = "cuda",
-                 need_backward: bool = True):
+                 need_backward: bool = True, grad_accum: int = 1):
         from .text import flatten_mapper_state
         self.cfg = cfg
         self.B, self.H, self.W = batch, height, width
@@ -80,7 +80,9 @@ class TrainStepEngine:
                 pv = flatten_mapper_state(mapper_view).to(device)
             mv = MapperState(pv, w_enc_view.to(device).float().contiguous(), norm_scale_view, alpha_view)
         # ---- device-resident scalars ----
-        self.hyper = torch.tensor([lr, betas[0], betas[1], adam_eps, weight_decay, float(world_size)],
+        self.grad_accum = grad_accum
+        # accelerate scales each micro-loss by 1/accum and DDP averages over ranks: fold both into AdamW
+        self.hyper = torch.tensor([lr, betas[0], betas[1], adam_eps, weight_decay, float(world_size * grad_accum)],
                                   dtype=torch.float32, device=device)
         self.scaler = torch.tensor([loss_scale, 0.0, 0.0], dtype=torch.float32, device=device)
         self.opt_step = torch.zeros(1, dtype=torch.int32, device=device)
@@ -101,7 +103,8 @@ class TrainStepEngine:
         self.latents = torch.zeros(shape, dtype=torch.float32, device=device)
         self.target = torch.zeros(shape, dtype=torch.float32, device=device)
         self.need_backward = need_backward
-        self.graph_a = self.graph_b = None
+        self.graph_a = self.graph_b = self.graph_acc = None
+        self.micro = 0
         self.n_loss = batch * Lc * self.h * self.w
 
     # ------------------------------------------------------------------ inputs
@@ -119,8 +122,9 @@ class TrainStepEngine:
         self.hyper[0] = lr
 
     # ------------------------------------------------------------------ the step
-    def forward_backward(self):
+    def forward_backward(self, accumulate: bool = False):
         B, Lc, hw = self.B, self.cfg.vae.latent_channels, self.h * self.w
+        self.text.accumulate_grads = accumulate
         if self.device_rng:
             ops.rng_advance(self.rng_state)
             ops.rng_fill_randint(self.timesteps, self.cfg.ddpm.num_train_timesteps, self.rng_state, 0)
@@ -148,39 +152,63 @@ class TrainStepEngine:
             all_reduce_sum_(self.grads)
 
     def step_eager(self):
-        self.forward_backward()
-        self.all_reduce()
-        self.optimizer_step()
+        """one micro-step; the optimizer runs after every `grad_accum`-th micro-step."""
+        self.forward_backward(accumulate=self.micro > 0)
+        self.micro += 1
+        if self.micro == self.grad_accum:
+            self.micro = 0
+            self.all_reduce()
+            self.optimizer_step()
+            return True
+        return False
 
     # ------------------------------------------------------------------ hipGraph capture
     def capture(self):
         """Capture the step into hipGraphs: [forward+backward] and [optimizer], with the RCCL
         all-reduce of the flat gradient bucket between them (single graph when world_size == 1)."""
+        # the warm-up launches below are real steps: snapshot the trainable / RNG state and put it back
+        state = [t.clone() for t in (self.params, self.exp_avg, self.exp_avg_sq, self.opt_step, self.scaler,
+                                     self.rng_state)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self.step_eager()  # warm-up on the side stream (also primes RCCL)
+            for _ in range(self.grad_accum):
+                self.step_eager()  # warm-up on the side stream (also primes RCCL)
             torch.cuda.synchronize()
+            fused_opt = self.world_size == 1 and self.grad_accum == 1
             self.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a, stream=s):
-                self.forward_backward()
-                if self.world_size == 1:
+                self.forward_backward(accumulate=False)
+                if fused_opt:
                     self.optimizer_step()
-            if self.world_size > 1:
+            if self.grad_accum > 1:
+                self.graph_acc = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_acc, stream=s):
+                    self.forward_backward(accumulate=True)
+            if not fused_opt:
                 self.graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_b, stream=s):
                     self.optimizer_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.opt_step, self.scaler, self.rng_state),
+                            state):
+            dst.copy_(src)
+        self.micro = 0
 
-    def step(self):
+    def step(self) -> bool:
+        """one micro-step (graph replay when captured); returns True when the optimizer stepped."""
         if self.graph_a is None:
-            self.step_eager()
-            return
-        self.graph_a.replay()
-        if self.world_size > 1:
+            return self.step_eager()
+        (self.graph_a if self.micro == 0 else self.graph_acc).replay()
+        self.micro += 1
+        if self.micro < self.grad_accum:
+            return False
+        self.micro = 0
+        if self.graph_b is not None:
             self.all_reduce()
             self.graph_b.replay()
+        return True
 
     def loss(self) -> float:
         """mean squared error of the last step (forces a device sync — call sparingly)."""

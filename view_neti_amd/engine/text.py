@@ -91,6 +91,7 @@ class TextEngine(Schedule):
         self.rows_view = torch.zeros((self.R,), dtype=torch.int32, device=device) if mapper_view else None
         self.view_params = self._buf((B, n_view_params), torch.float32, zero=True) if mapper_view else None
         self.hidden_mask_obj = None  # nested dropout masks may be installed by the trainer
+        self.accumulate_grads = False  # True on micro-steps 2..k of a gradient-accumulation group
         self.tok_emb = self._w32(weights["text_model.embeddings.token_embedding.weight"])
         self.pos_emb = self._w32(weights["text_model.embeddings.position_embedding.weight"])
         self._build(weights)
@@ -258,9 +259,9 @@ class TextEngine(Schedule):
         mo = self.mo
         bw.append(lambda: ops.mapper_bwd(mo.params, self.hidden_mask_obj, mo.norm_scale, self.bo["word"], self.dx0,
                                          self.rows_obj, D, self.bo["dbyp"], self.bo["save"], self.bo["rowg"], self.go,
-                                         False, R, mo.enc_dim, mo.hidden, D, True))
+                                         self.accumulate_grads, R, mo.enc_dim, mo.hidden, D, True))
         if self.train_view:
             mv = self.mv
-            bw.append(partial(ops.mapper_bwd, mv.params, None, mv.norm_scale, self.bv["word"], self.dx0,
-                              self.rows_view, D, self.bv["dbyp"], self.bv["save"], self.bv["rowg"], self.gv, False, R,
-                              mv.enc_dim, mv.hidden, D, True))
+            bw.append(lambda: ops.mapper_bwd(mv.params, None, mv.norm_scale, self.bv["word"], self.dx0,
+                                             self.rows_view, D, self.bv["dbyp"], self.bv["save"], self.bv["rowg"],
+                                             self.gv, self.accumulate_grads, R, mv.enc_dim, mv.hidden, D, True))
