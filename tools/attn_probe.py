@@ -1,0 +1,38 @@
+"""Dev tool: run the UNet's 64x64 self-attention (B=4,H=8,N=4096,D=40) fwd/bwd kernels a few times."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from view_neti_amd import ops
+B, H, N, D = 4, 8, int(os.environ.get("N", 4096)), int(os.environ.get("D", 40))
+Nk = int(os.environ.get("NK", N))
+C = H * D
+dev = "cuda"
+ops.set_default_gemm_workspace(torch.empty(16 * 2**20, dtype=torch.float32, device=dev))
+q = torch.randn(B * N, C, device=dev).half(); k = torch.randn(B * Nk, C, device=dev).half(); v = torch.randn(B * Nk, C, device=dev).half()
+do = torch.randn(B * N, C, device=dev).half()
+ld = (Nk + 7) // 8 * 8; ldq = (N + 7) // 8 * 8
+vt = torch.zeros(B, C, ld, device=dev, dtype=torch.float16); kt = torch.zeros_like(vt)
+qt = torch.zeros(B, C, ldq, device=dev, dtype=torch.float16); dot = torch.zeros_like(qt)
+ops.transpose(v, vt, Nk, C, B, C, Nk * C, ld, C * ld); ops.transpose(k, kt, Nk, C, B, C, Nk * C, ld, C * ld)
+ops.transpose(q, qt, N, C, B, C, N * C, ldq, C * ldq); ops.transpose(do, dot, N, C, B, C, N * C, ldq, C * ldq)
+o = torch.zeros_like(q); lse = torch.zeros(B, H, N, device=dev); delta = torch.zeros(B, H, N, device=dev)
+dq = torch.zeros_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(k)
+sc = D ** -0.5
+def run():
+    ops.attn_fwd(q, k, vt, o, lse, B, H, N, Nk, D, sc, False, ld)
+    ops.attn_bwd_delta(do, o, delta, B, H, N, D)
+    ops.attn_bwd_dq(q, k, kt, ld, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False)
+    ops.attn_bwd_dkv(q, qt, ldq, k, v, do, dot, ldq, lse, delta, dk, dv, B, H, N, Nk, D, sc, False)
+for _ in range(3): run()
+torch.cuda.synchronize()
+import time
+for name, fn in (("fwd", lambda: ops.attn_fwd(q, k, vt, o, lse, B, H, N, Nk, D, sc, False, ld)),
+                 ("dq", lambda: ops.attn_bwd_dq(q, k, kt, ld, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False)),
+                 ("dkv", lambda: ops.attn_bwd_dkv(q, qt, ldq, k, v, do, dot, ldq, lse, delta, dk, dv, B, H, N, Nk, D, sc, False))):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10): fn()
+    e.record(); torch.cuda.synchronize()
+    t = s.elapsed_time(e) / 10
+    fl = 4.0 * B * H * N * Nk * D * (1 if name == "fwd" else (2 if name == "dq" else 2.5)) / 1e9  # real (unpadded) GF
+    print(f"attn {name:4s} N={N} Nk={Nk} D={D}: {t*1e3:8.1f} us  {fl/t:7.1f} TF/s (unpadded flops)")

@@ -78,6 +78,28 @@ extern "C" __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void lab_ker
     if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
 #endif
     const char* As = smem + cur * STAGE_BYTES; const char* Bs = As + BM * 128;
+#ifdef FRAGDB
+    half8 afq[2][MI], bfq[2][NI];
+#define LOADFR(buf, ks)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) afq[buf][i] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, (ks) * 2 + fhalf))); \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) bfq[buf][j] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, (ks) * 2 + fhalf)));
+#define MMA(buf)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfq[buf][j], afq[buf][i], acc[i][j], 0, 0, 0);
+#ifdef SETPRIO
+#define PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PRIO(x)
+#endif
+    LOADFR(0, 0)
+    LOADFR(1, 1)
+    PRIO(1); MMA(0) PRIO(0);
+    LOADFR(0, 2)
+    PRIO(1); MMA(1) PRIO(0);
+    LOADFR(1, 3)
+    PRIO(1); MMA(0) PRIO(0);
+    PRIO(1); MMA(1) PRIO(0);
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       half8 af[MI], bf[NI];
@@ -104,6 +126,7 @@ extern "C" __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void lab_ker
       for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bf[j]));
 #endif
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }

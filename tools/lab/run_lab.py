@@ -2,18 +2,18 @@
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANTS = {
-    "64x64_s2": "-DBM=64 -DBN=64 -DWM=32 -DWN=32",
-    "64x64_s3": "-DBM=64 -DBN=64 -DWM=32 -DWN=32 -DSTAGES=3",
-    "64x64_s4": "-DBM=64 -DBN=64 -DWM=32 -DWN=32 -DSTAGES=4",
-    "128x64_s2": "-DBM=128 -DBN=64 -DWM=64 -DWN=32",
-    "128x64_s3": "-DBM=128 -DBN=64 -DWM=64 -DWN=32 -DSTAGES=3",
-    "128x64_s4": "-DBM=128 -DBN=64 -DWM=64 -DWN=32 -DSTAGES=4",
-    "128x128_s2": "",
-    "128x128_s3": "-DSTAGES=3",
-    "128x128_s4": "-DSTAGES=4",
-    "256x128_s2": "-DBM=256 -DBN=128",
-    "256x128_s3": "-DBM=256 -DBN=128 -DSTAGES=3",
-    "256x256_s2": "-DBM=256 -DBN=256",
+    "128x128": "",
+    "128x128_fragdb": "-DFRAGDB",
+    "128x128_fragdb_prio": "-DFRAGDB -DSETPRIO",
+    "128x64_fragdb": "-DBM=128 -DBN=64 -DWM=64 -DWN=32 -DFRAGDB",
+    "256x128_8w": "-DBM=256 -DBN=128",
+    "256x128_8w_fragdb": "-DBM=256 -DBN=128 -DFRAGDB",
+    "256x256_16w": "-DBM=256 -DBN=256",
+    "256x256_16w_fragdb": "-DBM=256 -DBN=256 -DFRAGDB",
+    "256x256_8w_128x64": "-DBM=256 -DBN=256 -DWM=128 -DWN=64",
+    "256x256_8w_128x64_fragdb": "-DBM=256 -DBN=256 -DWM=128 -DWN=64 -DFRAGDB",
+    "256x256_8w_128x64_fragdb_prio": "-DBM=256 -DBN=256 -DWM=128 -DWN=64 -DFRAGDB -DSETPRIO",
+    "256x128_4w_128x64_fragdb": "-DBM=256 -DBN=128 -DWM=128 -DWN=64 -DFRAGDB",
 }
 def build():
     for name, flags in VARIANTS.items():
@@ -23,7 +23,7 @@ def build():
         print(name, "ok" if r.returncode == 0 else r.stderr[-600:])
 def run():
     import torch
-    shapes = [(1024, 1280, 1280), (4096, 640, 640), (16384, 320, 320), (4928, 768, 768), (16384, 320, 2880), (4096, 4096, 4096)]
+    shapes = [(4096, 4096, 4096), (16384, 640, 5760), (16384, 320, 2880), (4096, 1280, 11520), (65536, 512, 4608), (4928, 3072, 768)]
     for name in VARIANTS:
         so = os.path.join(HERE, f"lab_{name}.so")
         if not os.path.exists(so):

@@ -46,6 +46,15 @@ struct AttnArgs {
   float* ws;    // [qsplit][2][Bn*Nk][H*D] f32
 };
 
+// raw v_exp_f32: the libm exp2 adds a 5-instruction denormal-range fix-up per element, which made
+// the softmax the bottleneck; flushing results below 2^-126 to zero is harmless here.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// online-softmax rescale threshold (natural-log units, expressed in log2 units at the use site):
+// the running max is only advanced when some row's max grew by more than this, so in steady state the
+// O/l rescale is skipped; P stays <= e^8 (fits f16, sums in f32).
+constexpr float RESCALE_THR_LOG2 = 8.0f * 1.4426950408889634f;
+
 __device__ __forceinline__ void zero_lds(char* smem, int bytes) {
   u32x4 z = {0u, 0u, 0u, 0u};
   for (int i = threadIdx.x * 16; i < bytes; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = z;
@@ -178,41 +187,47 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         s[aa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[aa], 0, 0, 0);
       }
     }
-    const bool need_mask = (key0 + 64 > a.Nk) || a.causal;
-    float mx = -INFINITY;
+    if ((key0 + 64 > a.Nk) || a.causal) {  // wave-uniform: only the tail / diagonal tiles pay for masking
 #pragma unroll
-    for (int aa = 0; aa < 2; ++aa) {
+      for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (need_mask) {
+        for (int r = 0; r < 16; ++r) {
           int key = key0 + aa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
           bool ok = key < a.Nk && (!a.causal || key <= q);
           if (!ok) s[aa][r] = -INFINITY;
         }
-        mx = fmaxf(mx, s[aa][r]);
-      }
     }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[aa][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f((m - m_use) * c);
-    const float mc = m_use * c;
+    if (!__all((mx - m) * c <= RESCALE_THR_LOG2)) {
+      // some row's max grew a lot (always true on the first tile): advance the running max and
+      // rescale everything accumulated so far, exactly once
+      const float m_new = fmaxf(m, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2((m - m_use) * c);
+      l *= alpha;
+      m = m_use;
+#pragma unroll
+      for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    }
+    const float mc = m * c;
     float psum = 0.f;
 #pragma unroll
     for (int aa = 0; aa < 2; ++aa) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = exp2f(s[aa][r] * c - mc);
+        float p = fast_exp2(s[aa][r] * c - mc);
         s[aa][r] = p;
         psum += p;
       }
     }
-    l = l * alpha + psum;
-    m = m_new;
-#pragma unroll
-    for (int i = 0; i < C::DB; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    l += psum;
 
 #pragma unroll
     for (int aa = 0; aa < 2; ++aa) {
@@ -399,16 +414,16 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnArgs a) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
       }
+      if (need_mask) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = exp2f(s[r] * c - lse2);
-        if (need_mask) {
+        for (int r = 0; r < 16; ++r) {
           int key = key0 + aa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
           bool ok = key < a.Nk && (!a.causal || key <= q);
-          if (!ok) p = 0.f;
+          if (!ok) s[r] = -INFINITY;
         }
-        s[r] = p * (dp[r] - dlt);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * c - lse2) * (dp[r] - dlt);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         half8 pf = cvt8(s, j);
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * qd + e;
-        float p = exp2f(s[r] * c - l4[e]);
+        float p = fast_exp2(s[r] * c - l4[e]);
         if (a.causal) {
           int qq = q0 + 8 * qd + 4 * h2 + e;
           if (key > qq) p = 0.f;

@@ -278,22 +278,36 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1, false);
     const char* As = smem + cur * STAGE_BYTES;
     const char* Bs = As + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      half8 af[MI], bf[NI];
+    // fragments double-buffered in registers: the ds_reads of k-step s+1 are in flight under the
+    // MFMAs of k-step s; on the 4-wave tiles the MFMA groups run at raised priority so the partner
+    // wave's loads/address math do not steal issue slots (+10..23 % in tools/lab).
+    half8 af[2][MI], bf[2][NI];
+    auto load_frags = [&](int buf, int ks) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-        af[i] = as_half8(*reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, ks * 2 + fhalf)));
+        af[buf][i] = as_half8(*reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, ks * 2 + fhalf)));
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        bf[j] = as_half8(*reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, ks * 2 + fhalf)));
+        bf[buf][j] = as_half8(*reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, ks * 2 + fhalf)));
+    };
+    auto mma = [&](int buf) {
+      if constexpr (NT == 256) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           // operands swapped: D[row = n][col = m]  => each lane owns 4 consecutive n of one m
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
+      if constexpr (NT == 256) __builtin_amdgcn_s_setprio(0);
+    };
+    load_frags(0, 0);
+    load_frags(1, 1);
+    mma(0);
+    load_frags(0, 2);
+    mma(1);
+    load_frags(1, 3);
+    mma(0);
+    mma(1);
     if (kt + 1 < kt_end) store_lds(cur ^ 1);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
