@@ -80,36 +80,51 @@ __device__ __forceinline__ half8 load_tfrag(const char* base, int row_bytes, int
 // forward
 // ============================================================================================
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+// min 2 blocks/CU caps the register budget at 256, which makes the compiler keep MFMA accumulators in
+// arch VGPRs (no v_accvgpr copies around the softmax VALU work)
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   using C = Cfg<D>;
+  // each wave owns QW independent 32-query sub-tiles: K/V fragments are read from LDS once and
+  // used QW times, and the two softmax/MFMA dependency chains interleave inside the wave
+  constexpr int QW = 1;  // 2 sub-tiles per wave measured slower (occupancy 1 wave/SIMD)
+  // when D is padded up to a multiple of 32, row D of the V^T tile is set to ones so the PV MFMA
+  // accumulates the softmax denominator for free (it rescales with O as well)
+  constexpr bool ONES = C::DB * 32 > D;
+  constexpr int L_DB = D / 32, L_R = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_H2 = ((D % 32) >> 2) & 1;
   constexpr int KS_BYTES = 64 * C::ROW;
   constexpr int VS_BYTES = C::DB * 32 * TROW64;
-  __shared__ __attribute__((aligned(16))) char smem[KS_BYTES + VS_BYTES];
-  char* Ks = smem;
-  char* Vs = smem + KS_BYTES;
+  constexpr int STAGE = KS_BYTES + VS_BYTES;  // two stages: the next tile is written while this one is read
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int qb0 = blockIdx.x * 128;
-  const int q = qb0 + wave * 32 + l31;
-  const bool qok = q < a.Nq;
+  const int qb0 = blockIdx.x * 128 * QW;
+  int q[QW];
+  bool qok[QW];
+#pragma unroll
+  for (int u = 0; u < QW; ++u) {
+    q[u] = qb0 + (wave * QW + u) * 32 + l31;
+    qok[u] = q[u] < a.Nq;
+  }
 
   __amdgpu_buffer_rsrc_t rsQ = vn_make_rsrc(a.Q, (uint32_t)((long long)a.Bn * a.Nq * a.ldq * 2));
   __amdgpu_buffer_rsrc_t rsK = vn_make_rsrc(a.K, (uint32_t)((long long)a.Bn * a.Nk * a.ldk * 2));
   __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.Vt, (uint32_t)((long long)a.Bn * a.H * D * a.ldvt * 2));
 
-  zero_lds(smem, KS_BYTES + VS_BYTES);
+  zero_lds(smem, 2 * STAGE);
 
-  half8 qf[C::KS];
+  half8 qf[QW][C::KS];
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) {
-    int ch = ks * 2 + h2;
-    uint32_t off = (qok && ch < C::DCH)
-                       ? (uint32_t)((((long long)b * a.Nq + q) * a.ldq + h * D + ch * 8) * 2)
-                       : VN_OOB;
-    qf[ks] = as_half8(vn_buf_load16(rsQ, off));
-  }
+  for (int u = 0; u < QW; ++u)
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      int ch = ks * 2 + h2;
+      uint32_t off = (qok[u] && ch < C::DCH)
+                         ? (uint32_t)((((long long)b * a.Nq + q[u]) * a.ldq + h * D + ch * 8) * 2)
+                         : VN_OOB;
+      qf[u][ks] = as_half8(vn_buf_load16(rsQ, off));
+    }
 
   constexpr int KIT = (64 * C::DCH + 255) / 256;
   constexpr int VIT = (D * 8 + 255) / 256;
@@ -138,7 +153,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       vreg[i] = vn_buf_load16(rsV, off);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    char* Ks = smem + buf * STAGE;
+    char* Vs = Ks + KS_BYTES;
 #pragma unroll
     for (int i = 0; i < KIT; ++i) {
       int idx = tid + 256 * i;
@@ -153,113 +170,146 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
   };
 
-  f32x16 o[C::DB];
+  f32x16 o[QW][C::DB];
+  float m[QW], l[QW];
 #pragma unroll
-  for (int i = 0; i < C::DB; ++i)
+  for (int u = 0; u < QW; ++u) {
+    m[u] = -INFINITY;
+    l[u] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-  float m = -INFINITY, l = 0.f;
+    for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[u][i][e] = 0.f;
+  }
   const float c = a.scale * LOG2E;
 
   int nkt = cdiv_dev(a.Nk, 64);
   if (a.causal) {
-    int lim = (min(qb0 + 127, a.Nq - 1)) / 64 + 1;
+    int lim = (min(qb0 + 128 * QW - 1, a.Nq - 1)) / 64 + 1;
     nkt = min(nkt, lim);
   }
 
   issue(0);
+  __syncthreads();  // LDS zero-fill visible
+  if constexpr (ONES) {
+    if (tid < 128)
+      *reinterpret_cast<half_t*>(smem + (tid >> 6) * STAGE + KS_BYTES + D * TROW64 + (tid & 63) * 2) = (half_t)1.f;
+  }
+  commit(0);
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    commit();
-    __syncthreads();
     if (kt + 1 < nkt) issue(kt + 1);
     const int key0 = kt * 64;
+    const char* Ks = smem + (kt & 1) * STAGE;
+    const char* Vs = Ks + KS_BYTES;
 
-    f32x16 s[2];
+    f32x16 s[QW][2];
+#pragma unroll
+    for (int u = 0; u < QW; ++u)
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[u][aa][e] = 0.f;
 #pragma unroll
     for (int aa = 0; aa < 2; ++aa) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[aa][e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         half8 kf = as_half8(
             *reinterpret_cast<const u32x4*>(Ks + (aa * 32 + l31) * C::ROW + (ks * 2 + h2) * 16));
-        s[aa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[aa], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < QW; ++u)
+          s[u][aa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][ks], s[u][aa], 0, 0, 0);
       }
     }
     if ((key0 + 64 > a.Nk) || a.causal) {  // wave-uniform: only the tail / diagonal tiles pay for masking
 #pragma unroll
+      for (int u = 0; u < QW; ++u)
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int key = key0 + aa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            bool ok = key < a.Nk && (!a.causal || key <= q[u]);
+            if (!ok) s[u][aa][r] = -INFINITY;
+          }
+    }
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+      float mx = -INFINITY;
+#pragma unroll
       for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int key = key0 + aa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-          bool ok = key < a.Nk && (!a.causal || key <= q);
-          if (!ok) s[aa][r] = -INFINITY;
-        }
-    }
-    float mx = -INFINITY;
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][aa][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (!__all((mx - m[u]) * c <= RESCALE_THR_LOG2)) {
+        // some row's max grew a lot (always true on the first tile): advance the running max and
+        // rescale everything accumulated so far, exactly once
+        const float m_new = fmaxf(m[u], mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2((m[u] - m_use) * c);
+        if constexpr (!ONES) l[u] *= alpha;
+        m[u] = m_use;
 #pragma unroll
-    for (int aa = 0; aa < 2; ++aa)
+        for (int i = 0; i < C::DB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[aa][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (!__all((mx - m) * c <= RESCALE_THR_LOG2)) {
-      // some row's max grew a lot (always true on the first tile): advance the running max and
-      // rescale everything accumulated so far, exactly once
-      const float m_new = fmaxf(m, mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = fast_exp2((m - m_use) * c);
-      l *= alpha;
-      m = m_use;
-#pragma unroll
-      for (int i = 0; i < C::DB; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-    }
-    const float mc = m * c;
-    float psum = 0.f;
-#pragma unroll
-    for (int aa = 0; aa < 2; ++aa) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = fast_exp2(s[aa][r] * c - mc);
-        s[aa][r] = p;
-        psum += p;
+          for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
       }
+      const float mc = m[u] * c;
+      float psum = 0.f;
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = fast_exp2(s[u][aa][r] * c - mc);
+          s[u][aa][r] = p;
+          if constexpr (!ONES) psum += p;
+        }
+      }
+      if constexpr (!ONES) l[u] += psum;
     }
-    l += psum;
 
 #pragma unroll
     for (int aa = 0; aa < 2; ++aa) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        half8 pf = cvt8(s[aa], j);
+        half8 pf[QW];
+#pragma unroll
+        for (int u = 0; u < QW; ++u) pf[u] = cvt8(s[u][aa], j);
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
           half8 vf = load_tfrag(Vs, TROW64, db * 32 + l31, aa * 32 + 16 * j + 4 * h2);
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[db], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < QW; ++u)
+            o[u][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[u][db], 0, 0, 0);
         }
       }
     }
+    if (kt + 1 < nkt) commit((kt + 1) & 1);
+    __syncthreads();
   }
 
-  l += __shfl_xor(l, 32, 64);
-  const float inv = (l > 0.f) ? 1.f / l : 0.f;
-  if (qok) {
-    half_t* orow = a.O + ((long long)b * a.Nq + q) * a.ldo + h * D;
 #pragma unroll
-    for (int db = 0; db < C::DB; ++db) {
+  for (int u = 0; u < QW; ++u) {
+    float lt;
+    if constexpr (ONES) lt = __shfl(o[u][L_DB][L_R], l31 + 32 * L_H2, 64);
+    else lt = l[u] + __shfl_xor(l[u], 32, 64);
+    const float inv = (lt > 0.f) ? 1.f / lt : 0.f;
+    if (qok[u]) {
+      half_t* orow = a.O + ((long long)b * a.Nq + q[u]) * a.ldo + h * D;
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        int d = db * 32 + 8 * qd + 4 * h2;
-        if (d < D) {
-          half4 v = {(half_t)(o[db][4 * qd] * inv), (half_t)(o[db][4 * qd + 1] * inv),
-                     (half_t)(o[db][4 * qd + 2] * inv), (half_t)(o[db][4 * qd + 3] * inv)};
-          *reinterpret_cast<half4*>(orow + d) = v;
+      for (int db = 0; db < C::DB; ++db) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          int d = db * 32 + 8 * qd + 4 * h2;
+          if (d < D) {
+            half4 v = {(half_t)(o[u][db][4 * qd] * inv), (half_t)(o[u][db][4 * qd + 1] * inv),
+                       (half_t)(o[u][db][4 * qd + 2] * inv), (half_t)(o[u][db][4 * qd + 3] * inv)};
+            *reinterpret_cast<half4*>(orow + d) = v;
+          }
         }
       }
+      if (h2 == 0 && a.lse) a.lse[((long long)b * a.H + h) * a.Nq + q[u]] = m[u] * a.scale + logf(lt);
     }
-    if (h2 == 0 && a.lse) a.lse[((long long)b * a.H + h) * a.Nq + q] = m * a.scale + logf(l);
   }
 }
 
@@ -294,14 +344,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
 //   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
 // ============================================================================================
 template <int D>
-__global__ __launch_bounds__(256) void attn_dq_kernel(AttnArgs a) {
+// min 2 blocks/CU caps the register budget at 256, which makes the compiler keep MFMA accumulators in
+// arch VGPRs (no v_accvgpr copies around the softmax VALU work)
+__global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
   using C = Cfg<D>;
   constexpr int KS_BYTES = 64 * C::ROW;
   constexpr int KT_BYTES = C::DB * 32 * TROW64;
-  __shared__ __attribute__((aligned(16))) char smem[2 * KS_BYTES + KT_BYTES];
-  char* Ks = smem;
-  char* Vs = smem + KS_BYTES;
-  char* Kts = smem + 2 * KS_BYTES;
+  constexpr int STAGE = 2 * KS_BYTES + KT_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h2 = lane >> 5;
@@ -316,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnArgs a) {
   __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.V, (uint32_t)((long long)a.Bn * a.Nk * a.ldv * 2));
   __amdgpu_buffer_rsrc_t rsKt = vn_make_rsrc(a.Kt, (uint32_t)((long long)a.Bn * a.H * D * a.ldkt * 2));
 
-  zero_lds(smem, 2 * KS_BYTES + KT_BYTES);
+  zero_lds(smem, 2 * STAGE);
 
   half8 qf[C::KS], dof[C::KS];
 #pragma unroll
@@ -363,7 +413,10 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnArgs a) {
       treg[i] = vn_buf_load16(rsKt, off);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    char* Ks = smem + buf * STAGE;
+    char* Vs = Ks + KS_BYTES;
+    char* Kts = Ks + 2 * KS_BYTES;
 #pragma unroll
     for (int i = 0; i < KIT; ++i) {
       int idx = tid + 256 * i;
@@ -391,12 +444,15 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnArgs a) {
   if (a.causal) nkt = min(nkt, (min(qb0 + 127, a.Nq - 1)) / 64 + 1);
 
   issue(0);
+  __syncthreads();
+  commit(0);
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    commit();
-    __syncthreads();
     if (kt + 1 < nkt) issue(kt + 1);
     const int key0 = kt * 64;
+    const char* Ks = smem + (kt & 1) * STAGE;
+    const char* Vs = Ks + KS_BYTES;
+    const char* Kts = Ks + 2 * KS_BYTES;
     const bool need_mask = (key0 + 64 > a.Nk) || a.causal;
 #pragma unroll
     for (int aa = 0; aa < 2; ++aa) {
@@ -434,6 +490,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnArgs a) {
         }
       }
     }
+    if (kt + 1 < nkt) commit((kt + 1) & 1);
+    __syncthreads();
   }
 
   if (qok) {
@@ -459,17 +517,14 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnArgs a) {
 //   dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
 // ============================================================================================
 template <int D>
-__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
+// min 2 blocks/CU caps the register budget at 256, which makes the compiler keep MFMA accumulators in
+// arch VGPRs (no v_accvgpr copies around the softmax VALU work)
+__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
   using C = Cfg<D>;
   constexpr int QS_BYTES = 32 * C::ROW;
   constexpr int QT_BYTES = C::DB * 32 * TROW32;
-  __shared__ __attribute__((aligned(16))) char smem[2 * QS_BYTES + 2 * QT_BYTES + 256];
-  char* Qs = smem;
-  char* dOs = smem + QS_BYTES;
-  char* Qts = smem + 2 * QS_BYTES;
-  char* dOts = Qts + QT_BYTES;
-  float* lses = reinterpret_cast<float*>(dOts + QT_BYTES);
-  float* dels = lses + 32;
+  constexpr int STAGE = 2 * QS_BYTES + 2 * QT_BYTES + 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h2 = lane >> 5;
@@ -487,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
   __amdgpu_buffer_rsrc_t rsQt = vn_make_rsrc(a.Qt, (uint32_t)((long long)a.Bn * a.H * D * a.ldqt * 2));
   __amdgpu_buffer_rsrc_t rsdOt = vn_make_rsrc(a.dOt, (uint32_t)((long long)a.Bn * a.H * D * a.lddot * 2));
 
-  zero_lds(smem, 2 * QS_BYTES + 2 * QT_BYTES + 256);
+  zero_lds(smem, 2 * STAGE);
 
   half8 kf[C::KS], vf[C::KS];
 #pragma unroll
@@ -545,7 +600,13 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    char* Qs = smem + buf * STAGE;
+    char* dOs = Qs + QS_BYTES;
+    char* Qts = Qs + 2 * QS_BYTES;
+    char* dOts = Qts + QT_BYTES;
+    float* lses = reinterpret_cast<float*>(dOts + QT_BYTES);
+    float* dels = lses + 32;
 #pragma unroll
     for (int i = 0; i < QIT; ++i) {
       int idx = tid + 256 * i;
@@ -585,12 +646,18 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
   const int qt0 = max(qs * per, a.causal ? min(kb0 / 32, nqt_all) : 0);
 
   if (qt0 < nqt) issue(qt0);
+  __syncthreads();
+  if (qt0 < nqt) commit(0);
+  __syncthreads();
   for (int qt = qt0; qt < nqt; ++qt) {
-    __syncthreads();
-    commit();
-    __syncthreads();
     if (qt + 1 < nqt) issue(qt + 1);
     const int q0 = qt * 32;
+    const char* Qs = smem + ((qt - qt0) & 1) * STAGE;
+    const char* dOs = Qs + QS_BYTES;
+    const char* Qts = Qs + 2 * QS_BYTES;
+    const char* dOts = Qts + QT_BYTES;
+    const float* lses = reinterpret_cast<const float*>(dOts + QT_BYTES);
+    const float* dels = lses + 32;
 
     f32x16 s, dp;
 #pragma unroll
@@ -634,6 +701,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnArgs a) {
         dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf, dk[db], 0, 0, 0);
       }
     }
+    if (qt + 1 < nqt) commit((qt + 1 - qt0) & 1);
+    __syncthreads();
   }
 
   if (a.qsplit > 1) {
