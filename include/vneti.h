@@ -188,6 +188,11 @@ int vneti_rng_fill_normal(void* out_f32, long long n, const void* state, unsigne
 int vneti_rng_fill_randint(void* out_i64, int n, int high, const void* state, unsigned stream_id,
                            void* stream);
 int vneti_rng_advance(void* state, void* stream);
+/* nested dropout of the mapper's hidden vector (models/neti_mapper.py:401-414): per mapper call
+ * (= per UNet layer) one Bernoulli(prob) draw; when it fires each sample gets a truncation index
+ * ~ U{0..hidden-1}.  mask: f32 [nl*Bn][hidden] of 0/1, the `hidden_mask` of vneti_mapper_fwd/_bwd. */
+int vneti_nested_dropout_mask(float* mask, int nl, int Bn, int hidden, float prob, const void* state,
+                              unsigned stream_id, void* stream);
 /* latent_dist.sample() * scaling_factor, DDPMScheduler.add_noise and the loss target
  * (training/coach.py:167-183,201-205) in one kernel.  moments: NHWC f16 [B][HW][ldm] (mean|logvar);
  * eps, noise, outputs: NCHW f32 [B][Lc][HW]. */
@@ -203,9 +208,26 @@ int vneti_mse_loss_grad(const void* pred, long long ldp, const float* target, vo
                         int HW, void* stream);
 /* torch.optim.AdamW over one flat f32 bucket with torch.cuda.amp.GradScaler semantics
  * (training/coach.py:214-218,750-756).  hyper = {lr, beta1, beta2, eps, weight_decay, grad_div};
- * scaler = {loss_scale, growth_tracker, found_inf}; step = int32 optimizer step count. */
+ * scaler = {loss_scale, growth_tracker, found_inf}; step = int32 optimizer step count.
+ * phases (bit mask) lets one optimizer step span several buckets: VNETI_OPT_CHECK = unscale-time
+ * inf/nan check of this bucket (sets found_inf), VNETI_OPT_APPLY = the update (skipped when
+ * found_inf), VNETI_OPT_FINISH = GradScaler.update() + step advance.  One bucket: pass all three.
+ * Several: CHECK every bucket, then APPLY every bucket, FINISH on the last call. */
+#define VNETI_OPT_CHECK 1
+#define VNETI_OPT_APPLY 2
+#define VNETI_OPT_FINISH 4
+#define VNETI_OPT_ALL 7
 int vneti_adamw_flat(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
-                     float* scaler, int* step, int growth_interval, void* stream);
+                     float* scaler, int* step, int growth_interval, int phases, void* stream);
+/* The same optimizer over a bucket of n_seg equal-length segments, one per mapper (learnable_mode 3:
+ * view mapper + one object mapper per scene, training/coach.py:505-598,750-756), keeping torch's
+ * per-parameter semantics: a segment enters the update set the first time it is `active` (has a
+ * gradient) and is stepped on every later iteration — with a zero gradient when inactive, because
+ * zero_grad() keeps zero tensors — using its own seg_step[] for the bias correction.
+ * active: device int32[n_active] segment ids that received gradients this step. */
+int vneti_adamw_segments(float* p, const float* g, float* m, float* v, long long seg_len, int n_seg,
+                         int* seg_step, const int* active, int n_active, const float* hyper,
+                         float* scaler, int* step, int growth_interval, int phases, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * NeTI text path
@@ -216,16 +238,21 @@ int vneti_adamw_flat(float* p, const float* g, float* m, float* v, long long n, 
  * (models/positional_encoding.py:146-195); params the flat f32 bucket in state_dict order
  * (net.0.{weight,bias}, net.1.*, net.3.*, net.4.*, output_layer.0.*).  hidden_mask (optional,
  * [R][hidden] of 0/1) expresses nested dropout / truncation (:401-414).  norm_scale <= 0 disables
- * the output normalisation (:434-436).  word/bypass: f32 [R][D]. */
+ * the output normalisation (:434-436).  word/bypass: f32 [R][D].  slot (optional device int32[1])
+ * selects one mapper of a bucket holding several (`mapper_object_lookup`,
+ * models/net_clip_text_embedding.py:65-76): params (and, in the backward, grads) are offset by
+ * slot[0]*slot_stride floats on the device, so the choice does not break hipGraph replay. */
 long long vneti_mapper_num_params(int enc_dim, int hidden, int D, int has_bypass);
 long long vneti_mapper_save_floats(int R, int enc_dim, int hidden);
 long long vneti_mapper_rowgrad_floats(int R, int hidden, int D, int has_bypass);
-int vneti_mapper_fwd(const float* params, const float* data, int nfeat, const float* w_enc,
+int vneti_mapper_fwd(const float* params, const int* slot, long long slot_stride, const float* data,
+                     int nfeat, const float* w_enc,
                      const float* hidden_mask, float norm_scale, float* word, float* bypass,
                      float* save, int R, int enc_dim, int hidden, int D, int has_bypass, void* stream);
 /* parameter gradients (the only wgrad of the whole train step).  d(word) for mapper row r is
  * read from dword_src + dword_rows[r]*ld_src (the placeholder rows of the embedding gradient). */
-int vneti_mapper_bwd(const float* params, const float* hidden_mask, float norm_scale,
+int vneti_mapper_bwd(const float* params, const int* slot, long long slot_stride,
+                     const float* hidden_mask, float norm_scale,
                      const float* word, const float* dword_src, const int* dword_rows,
                      long long ld_src, const float* dbypass, const float* save, float* rowgrads,
                      float* grads, int accumulate, int R, int enc_dim, int hidden, int D,
@@ -235,16 +262,21 @@ int vneti_mapper_bwd(const float* params, const float* hidden_mask, float norm_s
 int vneti_text_embed(const float* tok_emb, const float* pos_emb, const void* ids_i64,
                      const int* pos_obj, const float* word_obj, const int* pos_view,
                      const float* word_view, float* X, int nl, int Bn, int L, int D, void* stream);
-/* textual bypass + final_layer_norm on both variants (models/neti_clip_text_encoder.py:121-185,
- * constrained bypass): ctx_k = LN(last), ctx_v = LN(last with placeholder rows x + alpha b/|b| |x|) */
+/* textual bypass + final_layer_norm on both variants (models/neti_clip_text_encoder.py:121-185):
+ * ctx_k = LN(last), ctx_v = LN(last with the placeholder rows rewritten): constrained (:140-144)
+ * x + alpha b/|b| |x|; unconstrained (:145-149) b/|b| * detach(mean_j |x_j|), object first, then view.
+ * norm_terms: f32 [2][nl*Bn] scratch written by the forward and read by the backward (only
+ * needed when an unconstrained flag is set). */
 int vneti_text_final_fwd(const float* last, const float* gamma, const float* beta, float eps,
                          const int* pos_obj, const float* bypass_obj, float alpha_obj,
-                         const int* pos_view, const float* bypass_view, float alpha_view,
-                         void* ctx_k, void* ctx_v, int nl, int Bn, int L, int D, void* stream);
+                         int unconstrained_obj, const int* pos_view, const float* bypass_view,
+                         float alpha_view, int unconstrained_view, float* norm_terms, void* ctx_k,
+                         void* ctx_v, int nl, int Bn, int L, int D, void* stream);
 int vneti_text_final_bwd(const float* last, const float* gamma, float eps, const int* pos_obj,
-                         const float* bypass_obj, float alpha_obj, float* dbypass_obj,
-                         const int* pos_view, const float* bypass_view, float alpha_view,
-                         float* dbypass_view, const void* dctx_k, const void* dctx_v, float* dX,
+                         const float* bypass_obj, float alpha_obj, int unconstrained_obj,
+                         float* dbypass_obj, const int* pos_view, const float* bypass_view,
+                         float alpha_view, int unconstrained_view, float* dbypass_view,
+                         const float* norm_terms, const void* dctx_k, const void* dctx_v, float* dX,
                          int nl, int Bn, int L, int D, void* stream);
 /* conditioning inputs of the mapper for every (layer, sample) row:
  * data[(l,b)] = [t_b/1000*2-1, l/nl*2-1, view_params[b][0..nv)]  (models/neti_mapper.py:545-562) */

@@ -374,19 +374,23 @@ def get_velocity(ac: torch.Tensor, x0, noise, t):
 # the train step (Coach.train body, training/coach.py:154-218) for learnable_mode 0
 # ------------------------------------------------------------------------------------------
 def text_conditioning(clip_w: W, clip_cfg, mapper_p: W, w_enc, norm_scale, input_ids, placeholder_object,
-                      timesteps, alpha=0.2, unconstrained=False, n_layers=16, view=None):
+                      timesteps, alpha=0.2, unconstrained=False, n_layers=16, view=None, hidden_masks=None):
     """Coach.get_text_conditioning (training/coach.py:276-311): one text-encoder pass per UNet
     cross-attention layer; returns the XTI context dict.
-    view = optional dict(p, w_enc, norm_scale, placeholder, params, alpha, unconstrained)."""
+    view = optional dict(p, w_enc, norm_scale, placeholder, params, alpha, unconstrained, hidden_masks).
+    hidden_masks: optional [n_layers, B, hidden] 0/1 nested-dropout masks (neti_mapper.py:401-414)."""
     hs = {"this_idx": 0}
     B = input_ids.shape[0]
     for l in range(n_layers):
         layer = torch.full((B,), float(l))
-        word, byp = mapper_forward(mapper_p, w_enc, timesteps, layer, norm_scale, True, n_layers)
+        word, byp = mapper_forward(mapper_p, w_enc, timesteps, layer, norm_scale, True, n_layers,
+                                   truncation_mask=None if hidden_masks is None else hidden_masks[l])
         kw = {}
         if view is not None:
+            vm = view.get("hidden_masks")
             wv, bv = mapper_forward(view["p"], view["w_enc"], timesteps, layer, view["norm_scale"], True,
-                                    n_layers, view_params=view["params"])
+                                    n_layers, view_params=view["params"],
+                                    truncation_mask=None if vm is None else vm[l])
             kw = dict(placeholder_view=view["placeholder"], word_view=wv, bypass_view=bv,
                       unconstrained_view=view.get("unconstrained", False), alpha_view=view.get("alpha", alpha))
         last, last_b = neti_text_encoder(clip_w, clip_cfg, input_ids, placeholder_object, word, byp,

@@ -15,7 +15,7 @@ def build(cfg_name, B, H, W, with_view=False, **kw):
     from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
     cfg = sc.CONFIGS[cfg_name]()
     dev = "cuda"
-    gpu = cfg_name != "tiny"
+    gpu = not cfg_name.startswith("tiny")
     uw = synth.unet_weights(cfg.unet, device=dev if gpu else "cpu")
     vw = synth.vae_weights(cfg.vae, device=dev if gpu else "cpu")
     cw = synth.clip_weights(cfg.clip, device=dev if gpu else "cpu")
@@ -35,14 +35,19 @@ def build(cfg_name, B, H, W, with_view=False, **kw):
     return cfg, eng, (uw, vw, cw), sd, w_enc, extra
 
 
-@pytest.mark.parametrize("with_view", [False, True])
-def test_train_step_tiny_matches_oracle(with_view):
+# config 2 (mode 0, SD-1.5 family) / config 3 (mode 2: object + view mappers) / SD-2.1 family switches
+# (linear projections, GELU CLIP, v-prediction; non-square DTU-like frame) / unconstrained bypass
+@pytest.mark.parametrize("cfg_name,with_view,H,W,unc", [("tiny", False, 64, 64, False), ("tiny", True, 64, 64, False),
+                                                        ("tiny21", True, 64, 128, False),
+                                                        ("tiny21", True, 64, 64, True)])
+def test_train_step_tiny_matches_oracle(cfg_name, with_view, H, W, unc):
     from oracle import sd_ref as R
     from view_neti_amd import synth
     from view_neti_amd.engine.text import flatten_mapper_state
-    B, H, W = 2, 64, 64
+    B = 2
     lr = 4e-3
-    cfg, eng, (uw, vw, cw), sd, w_enc, extra = build("tiny", B, H, W, with_view, device_rng=False, lr=lr)
+    cfg, eng, (uw, vw, cw), sd, w_enc, extra = build(cfg_name, B, H, W, with_view, device_rng=False, lr=lr,
+                                                     unconstrained_object=unc, unconstrained_view=unc)
     ph = cfg.clip.vocab_size - 3
     phv = cfg.clip.vocab_size - 4
     ids = synth.input_ids(B, ph, cfg.clip.vocab_size, view_placeholder_id=phv if with_view else None)
@@ -65,9 +70,9 @@ def test_train_step_tiny_matches_oracle(with_view):
     if with_view:
         p_v = {k: v.clone().requires_grad_(True) for k, v in extra["mapper_view"].items()}
         view = dict(p=p_v, w_enc=extra["w_enc_view"], norm_scale=0.35, placeholder=torch.full((B,), phv),
-                    params=vparams, alpha=0.3)
+                    params=vparams, alpha=0.3, unconstrained=unc)
     loss, aux = R.train_step_loss(cfg, r16(uw), r16(vw), r16(cw), p_o, w_enc, 0.4, px, ids, torch.full((B,), ph), t,
-                                  eps, noise, alpha=0.2, view=view)
+                                  eps, noise, alpha=0.2, unconstrained=unc, view=view)
     loss.backward()
     ref = [flatten_mapper_state({k: v.grad for k, v in p_o.items()})]
     if with_view:
@@ -77,7 +82,7 @@ def test_train_step_tiny_matches_oracle(with_view):
     cos = torch.nn.functional.cosine_similarity(grads_gpu, ref_g, dim=0).item()
     gerr = ((grads_gpu - ref_g).norm() / ref_g.norm()).item()
     lat = ((eng.latents.cpu() - aux["latents"]).norm() / aux["latents"].norm()).item()
-    print(f"[step tiny view={with_view}] loss gpu {loss_gpu:.6f} oracle {loss.item():.6f} rel {rel:.2e}; "
+    print(f"[step {cfg_name} {H}x{W} view={with_view} unc={unc}] loss gpu {loss_gpu:.6f} oracle {loss.item():.6f} rel {rel:.2e}; "
           f"latents rel {lat:.2e}; grad cos {cos:.6f} rel {gerr:.2e} |g| {ref_g.norm():.3e}")
     assert rel < 1e-3, "predicted-noise MSE must match the oracle to 1e-3 relative"
     assert cos > 0.999 and gerr < 5e-2
@@ -111,3 +116,59 @@ def test_graph_replay_equals_eager_and_trains():
     assert ts[0] != ts[1], "device RNG must advance between replays"
     assert not torch.equal(p0, eng.params) and torch.isfinite(eng.params).all()
     assert eng.opt_step.item() == 6  # capture() must not leave a warm-up update behind
+
+
+def test_multi_object_mappers_and_segmented_adamw():
+    """learnable_mode 3 (BASELINE config 4): several object mappers + one view mapper in one bucket; the
+    batch's scene picks the object mapper on the device (graph replay safe); AdamW keeps torch's
+    per-parameter semantics (untouched mappers are skipped, touched ones keep decaying with zero grad)."""
+    from view_neti_amd import synth
+    from view_neti_amd.engine.step import TrainStepEngine
+    from view_neti_amd.engine.text import flatten_mapper_state
+    from view_neti_amd import sd_config as sc
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    B, H, W, K, lr = 2, 64, 64, 3, 2e-3
+    cfg = sc.tiny()
+    D = cfg.clip.hidden_size
+    gen = torch.Generator().manual_seed(7)
+    mk = lambda: {k: v + 0.05 * torch.randn(v.shape, generator=gen) for k, v in init_mapper_state(64, 64, D).items()}
+    objs = [mk() for _ in range(K)]
+    sdv = mk()
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    w_enc_v = fourier_frequencies([0.03, 2.0] + [0.5] * 12, 64, 0)
+    eng = TrainStepEngine(cfg, synth.unet_weights(cfg.unet), synth.vae_weights(cfg.vae), synth.clip_weights(cfg.clip), B,
+                          H, W, objs, w_enc, 0.4, 0.2, mapper_view=sdv, w_enc_view=w_enc_v, norm_scale_view=0.35,
+                          alpha_view=0.3, lr=lr, seed=11, device_rng=True)
+    n = eng.n_obj
+    assert eng.n_objects == K and eng.params.numel() == (K + 1) * n
+    ph, phv = cfg.clip.vocab_size - 3, cfg.clip.vocab_size - 4
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size, view_placeholder_id=phv)
+    vparams = synth.gaussian((B, 12), 9).clamp(-1, 1)
+    px = synth.pixel_values(B, H, W)
+    # torch reference optimizer over [obj_0, obj_1, obj_2, view] with zero_grad(set_to_none=False)
+    ref = [torch.nn.Parameter(eng.params[i * n:(i + 1) * n].cpu().clone()) for i in range(K + 1)]
+    opt = torch.optim.AdamW(ref, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    eng.capture()
+    order = [0, 2, 2, 0, 1]
+    for it, k in enumerate(order):
+        eng.set_batch(px, ids, torch.full((B,), ph), torch.full((B,), phv), vparams, object_index=k)
+        before = eng.params.clone()
+        eng.step()
+        torch.cuda.synchronize()
+        g = (eng.grads / (eng.scaler[0] * eng.hyper[5])).cpu()
+        assert torch.isfinite(g).all() and g[k * n:(k + 1) * n].abs().sum() > 0 and g[K * n:].abs().sum() > 0
+        opt.zero_grad(set_to_none=False)
+        ref[k].grad = g[k * n:(k + 1) * n].clone()
+        ref[K].grad = g[K * n:].clone()
+        opt.step()
+        touched = sorted(set(order[: it + 1]))
+        for j in range(K):
+            moved = not torch.equal(before[j * n:(j + 1) * n], eng.params[j * n:(j + 1) * n])
+            assert moved == (j in touched), f"step {it}: object mapper {j} moved={moved}, touched so far {touched}"
+    got = eng.params.cpu()
+    want = torch.cat([p.detach() for p in ref])
+    err = ((got - want).abs().max() / lr).item()
+    print(f"[mode3] {K} object mappers + view, order {order}: max |dp|/lr vs torch.optim.AdamW {err:.3e}; "
+          f"seg_step {eng.seg_step.tolist()} opt_step {eng.opt_step.item()}")
+    assert err < 0.05
+    assert eng.seg_step.tolist() == [5, 1, 4] and eng.opt_step.item() == len(order)

@@ -13,8 +13,13 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-20)).item()
 
 
-@pytest.mark.parametrize("with_view", [False, True])
-def test_text_engine_tiny(with_view):
+# (view mapper?, object bypass unconstrained?, view bypass unconstrained?, nested dropout?)
+VARIANTS = [(False, False, False, False), (True, False, False, False), (False, True, False, False),
+            (True, True, True, False), (True, False, True, True), (False, False, False, True)]
+
+
+@pytest.mark.parametrize("with_view,unc_obj,unc_view,dropout", VARIANTS)
+def test_text_engine_tiny(with_view, unc_obj, unc_view, dropout):
     from oracle import sd_ref as R
     from view_neti_amd import sd_config as sc, synth
     from view_neti_amd.engine.text import MapperState, TextEngine, flatten_mapper_state
@@ -49,7 +54,9 @@ def test_text_engine_tiny(with_view):
     ts = t.to(dev)
     po = flatten_mapper_state(sdo).to(dev)
     go = torch.zeros_like(po)
-    mo = MapperState(po, w_enc_o.to(dev), 0.4, 0.2)
+    pdrop = 0.5 if dropout else 0.0
+    rng_state = torch.tensor([77, 5], dtype=torch.int32, device=dev)
+    mo = MapperState(po, w_enc_o.to(dev), 0.4, 0.2, unconstrained=unc_obj, nested_dropout_prob=pdrop)
     kw = {}
     view = None
     if with_view:
@@ -57,25 +64,42 @@ def test_text_engine_tiny(with_view):
         vparams = torch.rand(B, 12, generator=gen) * 2 - 1
         pv = flatten_mapper_state(sdv).to(dev)
         gv = torch.zeros_like(pv)
-        kw = dict(mapper_view=MapperState(pv, w_enc_v.to(dev), 0.35, 0.3), grads_view=gv)
-    eng = TextEngine(cfg, wr, nl, B, ts, ctx_k, ctx_v, dk.to(dev), dv.to(dev), mo, go, **kw)
+        kw = dict(mapper_view=MapperState(pv, w_enc_v.to(dev), 0.35, 0.3, unconstrained=unc_view,
+                                          nested_dropout_prob=pdrop), grads_view=gv)
+    eng = TextEngine(cfg, wr, nl, B, ts, ctx_k, ctx_v, dk.to(dev), dv.to(dev), mo, go, rng_state=rng_state, **kw)
     eng.set_batch(ids, torch.full((B,), ph_obj), torch.full((B,), ph_view) if with_view else None,
                   vparams if with_view else None)
     eng.forward()
     eng.backward()
     torch.cuda.synchronize()
+    # ---- nested-dropout masks drawn on the device: structure check, then hand them to the oracle ----
+    masks_o = masks_v = None
+    if dropout:
+        def check(mask):
+            m = mask.cpu().view(nl, B, -1)
+            assert set(m.unique().tolist()) <= {0.0, 1.0}
+            kept = m.sum(-1)
+            # a prefix of ones per row (hidden[idx:] = 0), whole layers either fire or not
+            assert bool((m[..., :-1] >= m[..., 1:]).all())
+            fired = (kept < m.shape[-1]).any(1)
+            assert 0 < int(fired.sum()) < nl, "p=0.5 over 16 layers: some but not all mapper calls drop"
+            return m
+        masks_o = check(eng.hidden_mask_obj)
+        if with_view:
+            masks_v = check(eng.hidden_mask_view)
+            assert not torch.equal(masks_o, masks_v)
     # ---- oracle ----
     p_o = {k: v.clone().requires_grad_(True) for k, v in sdo.items()}
     if with_view:
         p_v = {k: v.clone().requires_grad_(True) for k, v in sdv.items()}
         view = dict(p=p_v, w_enc=w_enc_v, norm_scale=0.35, placeholder=torch.full((B,), ph_view), params=vparams,
-                    alpha=0.3)
-    hs = R.text_conditioning(wr, cfg, p_o, w_enc_o, 0.4, ids, torch.full((B,), ph_obj), t, alpha=0.2, n_layers=nl,
-                             view=view)
+                    alpha=0.3, unconstrained=unc_view, hidden_masks=masks_v)
+    hs = R.text_conditioning(wr, cfg, p_o, w_enc_o, 0.4, ids, torch.full((B,), ph_obj), t, alpha=0.2,
+                             unconstrained=unc_obj, n_layers=nl, view=view, hidden_masks=masks_o)
     rk = torch.stack([hs[f"CONTEXT_TENSOR_{i}"] for i in range(nl)]).reshape(nl, B * L, D)
     rv = torch.stack([hs[f"CONTEXT_TENSOR_BYPASS_{i}"] for i in range(nl)]).reshape(nl, B * L, D)
     ek, ev = _rel(ctx_k, rk.detach()), _rel(ctx_v, rv.detach())
-    print(f"[text view={with_view}] ctx_k rel {ek:.3e}  ctx_v rel {ev:.3e}")
+    print(f"[text view={with_view} unc={unc_obj}/{unc_view} drop={dropout}] ctx_k rel {ek:.3e}  ctx_v rel {ev:.3e}")
     assert ek < 5e-3 and ev < 5e-3
     ((rk * dk.float()).sum() + (rv * dv.float()).sum()).backward()
     ref_g = flatten_mapper_state({k: v.grad for k, v in p_o.items()})

@@ -35,12 +35,15 @@ tot += timed("text.backward", eng.text.backward)
 tot += timed("optimizer", eng.optimizer_step)
 print(f"{'sum':18s} {tot:8.3f} ms")
 timed("whole step", eng.step_eager)
+eng.overlap = False
+timed("whole (1 stream)", eng.step_eager)
+eng.overlap = True
 # kernel-class breakdown inside the UNet
 from view_neti_amd import ops
 def cls(f):
     fn = getattr(f, "func", None)
     return getattr(fn, "__name__", "lambda")
-for nm, lst in (("vae.fwd", eng.vae.fwd), ("text.fwd", eng.text.fwd), ("unet.fwd", eng.unet.fwd), ("unet.bwd", eng.unet.bwd), ("text.bwd", eng.text.bwd)):
+for nm, lst in (("vae.fwd", eng.vae.fwd), ("text.fwd", eng.text.fwd), ("unet.pre", eng.unet.fwd_pre), ("unet.fwd", eng.unet.fwd), ("unet.bwd", eng.unet.bwd), ("text.bwd", eng.text.bwd)):
     groups = {}
     for f in lst: groups.setdefault(cls(f), []).append(f)
     line = f"{nm:9s}"

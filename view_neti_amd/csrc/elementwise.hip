@@ -168,6 +168,21 @@ __global__ void fill_randint_kernel(long long* out, int n, int high, const uint3
   h = hash_u32(h ^ (state[1] * 0x85EBCA6BU + 0x27D4EB2FU));
   out[gid] = (long long)(h % (uint32_t)high);
 }
+// nested dropout (models/neti_mapper.py:401-414): one Bernoulli(prob) draw per mapper call (= per UNet
+// layer l); when it fires every sample b gets its own truncation index ~ U{0..hidden-1} and the
+// hidden vector is zeroed from there on.  mask[(l,b)][j] = 1 if kept.
+__global__ void nested_dropout_mask_kernel(float* mask, int nl, int Bn, int hidden, float prob,
+                                           const uint32_t* state, uint32_t stream_id) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= nl * Bn * hidden) return;
+  const int j = gid % hidden, r = gid / hidden, l = r / Bn;
+  const uint32_t seed = state[0] + stream_id * 0x9E3779B9U;
+  uint32_t hl = hash_u32(hash_u32((uint32_t)l * 0x9E3779B1U + seed) ^ (state[1] * 0x85EBCA6BU + 0x27D4EB2FU));
+  const bool fire = (float)(hl >> 8) * (1.f / 16777216.f) < prob;
+  uint32_t hr = hash_u32(hash_u32((uint32_t)(r + 0x10000) * 0x9E3779B1U + seed) ^ (state[1] * 0x85EBCA6BU + 0x27D4EB2FU));
+  const int idx = (int)(hr % (uint32_t)hidden);
+  mask[gid] = (!fire || j < idx) ? 1.f : 0.f;
+}
 __global__ void rng_advance_kernel(uint32_t* state) {
   if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += 1u;
 }
@@ -254,6 +269,52 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
   p[gid] = pv - (lr / bc1) * mv / denom;
   m[gid] = mv;
   v[gid] = vv;
+}
+// AdamW over a bucket of equal-length segments (one per mapper) with torch's per-parameter state:
+// a segment joins the update set the first time it receives a gradient (grad None -> skipped,
+// torch/optim/adamw.py) and from then on is stepped every iteration, with a zero gradient when it
+// was not in the batch (zero_grad() keeps zero tensors in torch 1.13), each with its own `step`.
+__global__ __launch_bounds__(256) void adamw_segments_kernel(float* p, const float* g, float* m, float* v,
+                                                             long long n, long long seg_len, const int* seg_step,
+                                                             const int* active, int n_active, const float* hyper,
+                                                             const float* scaler) {
+  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n) return;
+  if (scaler[2] != 0.f) return;
+  const int seg = (int)(gid / seg_len);
+  bool is_active = false;
+  for (int i = 0; i < n_active; ++i) is_active |= active[i] == seg;
+  const int t0 = seg_step[seg];
+  if (t0 == 0 && !is_active) return;  // never had a gradient: not in the optimizer's update set yet
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gdiv = hyper[5];
+  const int t = t0 + 1;
+  float grad = is_active ? g[gid] / (scaler[0] * gdiv) : 0.f;
+  float pv = p[gid] * (1.f - lr * wd);
+  float mv = b1 * m[gid] + (1.f - b1) * grad;
+  float vv = b2 * v[gid] + (1.f - b2) * grad * grad;
+  float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
+  float denom = sqrtf(vv) / sqrtf(bc2) + eps;
+  p[gid] = pv - (lr / bc1) * mv / denom;
+  m[gid] = mv;
+  v[gid] = vv;
+}
+__global__ void segments_step_kernel(int* seg_step, int n_seg, const int* active, int n_active, const float* scaler) {
+  int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= n_seg || scaler[2] != 0.f) return;
+  bool is_active = false;
+  for (int i = 0; i < n_active; ++i) is_active |= active[i] == seg;
+  if (seg_step[seg] > 0 || is_active) seg_step[seg] += 1;
+}
+// finite check restricted to the active segments (the others hold stale or zero gradients)
+__global__ __launch_bounds__(256) void grads_check_finite_segments_kernel(const float* g, long long seg_len,
+                                                                          const int* active, float* scaler) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  if (i < seg_len) {
+    float x = g[(long long)active[blockIdx.y] * seg_len + i];
+    bad = !(fabsf(x) <= 3.0e38f);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) scaler[2] = 1.f;
 }
 // GradScaler.update(): backoff 0.5 on inf, growth x2 every `interval` clean steps; advance step
 __global__ void scaler_update_kernel(float* scaler, int* step, int growth_interval) {
@@ -352,6 +413,16 @@ extern "C" int vneti_rng_fill_randint(void* out, int n, int high, const void* st
   return vneti_check_launch("rng_fill_randint");
 }
 
+extern "C" int vneti_nested_dropout_mask(float* mask, int nl, int Bn, int hidden, float prob, const void* state,
+                                         unsigned stream_id, void* stream) {
+  VN_REQUIRE(mask && state && nl > 0 && Bn > 0 && hidden > 0 && prob >= 0.f && prob <= 1.f,
+             "nested_dropout_mask: bad arguments");
+  int n = nl * Bn * hidden;
+  hipLaunchKernelGGL(nested_dropout_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, mask, nl, Bn, hidden, prob,
+                     (const uint32_t*)state, (uint32_t)stream_id);
+  return vneti_check_launch("nested_dropout_mask");
+}
+
 extern "C" int vneti_rng_advance(void* state, void* stream) {
   VN_REQUIRE(state, "rng_advance: null state");
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, ST, (uint32_t*)state);
@@ -381,13 +452,35 @@ extern "C" int vneti_mse_loss_grad(const void* pred, long long ldp, const float*
   return vneti_check_launch("mse_loss_grad");
 }
 
+extern "C" int vneti_adamw_segments(float* p, const float* g, float* m, float* v, long long seg_len, int n_seg,
+                                    int* seg_step, const int* active, int n_active, const float* hyper,
+                                    float* scaler, int* step, int growth_interval, int phases, void* stream) {
+  VN_REQUIRE(p && g && m && v && hyper && scaler && step && seg_step && active && seg_len > 0 && n_seg > 0 &&
+                 n_active > 0 && n_active <= 8 && phases > 0 && phases < 8,
+             "adamw_segments: bad arguments");
+  const long long n = seg_len * n_seg;
+  if (phases & 1)
+    hipLaunchKernelGGL(grads_check_finite_segments_kernel, dim3((unsigned)cdivl(seg_len, 256), n_active), dim3(256),
+                       0, ST, g, seg_len, active, scaler);
+  if (phases & 2) {
+    hipLaunchKernelGGL(adamw_segments_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, ST, p, g, m, v, n, seg_len,
+                       (const int*)seg_step, active, n_active, hyper, (const float*)scaler);
+    hipLaunchKernelGGL(segments_step_kernel, dim3(cdiv(n_seg, 256)), dim3(256), 0, ST, seg_step, n_seg, active,
+                       n_active, (const float*)scaler);
+  }
+  if (phases & 4) hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, ST, scaler, step, growth_interval);
+  return vneti_check_launch("adamw_segments");
+}
+
 extern "C" int vneti_adamw_flat(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
-                                float* scaler, int* step, int growth_interval, void* stream) {
-  VN_REQUIRE(p && g && m && v && hyper && scaler && step && n > 0, "adamw_flat: bad arguments");
+                                float* scaler, int* step, int growth_interval, int phases, void* stream) {
+  VN_REQUIRE(p && g && m && v && hyper && scaler && step && n > 0 && phases > 0 && phases < 8,
+             "adamw_flat: bad arguments");
   unsigned blocks = (unsigned)cdivl(n, 256);
-  hipLaunchKernelGGL(grads_check_finite_kernel, dim3(blocks), dim3(256), 0, ST, g, n, scaler);
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, hyper, (const float*)scaler,
-                     (const int*)step);
-  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, ST, scaler, step, growth_interval);
+  if (phases & 1) hipLaunchKernelGGL(grads_check_finite_kernel, dim3(blocks), dim3(256), 0, ST, g, n, scaler);
+  if (phases & 2)
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, hyper, (const float*)scaler,
+                       (const int*)step);
+  if (phases & 4) hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, ST, scaler, step, growth_interval);
   return vneti_check_launch("adamw_flat");
 }

@@ -48,6 +48,7 @@ __device__ void block_layernorm(float* z, const float* gamma, const float* beta,
 
 // one block (256 threads) per mapper row r = (layer, sample)
 __global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const float* __restrict__ params,
+                                                         const int* __restrict__ slot, long long slot_stride,
                                                          const float* __restrict__ data, int nfeat,
                                                          const float* __restrict__ w_enc,
                                                          const float* __restrict__ hmask, float norm_scale,
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const 
                                                          float* __restrict__ save) {
   __shared__ float enc[MAXH], z[MAXH], xh[MAXH], y[MAXH], a[MAXH], stat[2], red[4];
   const int r = blockIdx.x, tid = threadIdx.x;
+  if (slot) params += (long long)slot[0] * slot_stride;  // which mapper of a multi-mapper bucket (device-side)
   const int E = mp.E, hd = mp.hd, D = mp.D;
   // per-row save area: enc[E] | xh1[hd] | a1[hd] | xh2[hd] | a2m[hd] | rstd1, rstd2, wnorm, pad
   float* sv = save + (long long)r * (E + 4 * hd + 4);
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const 
 // backward stage 1: per row, from (d_word, d_bypass) down to the pre-LayerNorm gradients.
 // rowgrads layout per row: dout[OD] | dz2[hd] | dy2[hd] | dz1[hd] | dy1[hd]
 __global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, const float* __restrict__ params,
+                                                              const int* __restrict__ slot, long long slot_stride,
                                                               const float* __restrict__ hmask, float norm_scale,
                                                               const float* __restrict__ word,
                                                               const float* __restrict__ dword_src,
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, c
                                                               float* __restrict__ rowgrads) {
   __shared__ float dout[2048 + 64], part[4][MAXH], dz[MAXH], da[MAXH], red[4], st[2];
   const int r = blockIdx.x, tid = threadIdx.x;
+  if (slot) params += (long long)slot[0] * slot_stride;
   const int E = mp.E, hd = mp.hd, D = mp.D, OD = mp.OD;
   const float* sv = save + (long long)r * (E + 4 * hd + 4);
   float* rg = rowgrads + (long long)r * (OD + 4 * hd);
@@ -225,9 +229,11 @@ __global__ __launch_bounds__(256) void mapper_bwd_reduce_kernel(MapperParams mp,
                                                                 const float* __restrict__ save,
                                                                 const float* __restrict__ rowgrads,
                                                                 float* __restrict__ grads, int nparams,
-                                                                int accumulate) {
+                                                                int accumulate, const int* __restrict__ slot,
+                                                                long long slot_stride) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= nparams) return;
+  if (slot) grads += (long long)slot[0] * slot_stride;
   const int E = mp.E, hd = mp.hd, OD = mp.OD;
   const int ssz = E + 4 * hd + 4, gsz = OD + 4 * hd;
   // which tensor?
@@ -404,7 +410,56 @@ struct BypassArgs {
   const float* b;      // [nl*B][D] bypass vectors
   float* db;           // [nl*B][D] gradient (backward only)
   float alpha;
+  const float* nterm;  // [nl*B] detached mean row norm (unconstrained bypass) or null (constrained)
 };
+
+// normalizing terms of the unconstrained bypass (neti_clip_text_encoder.py:145-149,168-172): per
+// (layer, sample) the mean over the L token rows of |row|, taken on the tensor *as it is when the
+// mapper's turn comes*: the view term sees the object row already replaced.
+// nterm[0][(l,b)] = object term, nterm[1][(l,b)] = view term.
+__global__ __launch_bounds__(256) void text_norm_terms_kernel(const float* __restrict__ last, BypassArgs obj,
+                                                              int obj_unc, float* __restrict__ nterm, int nl, int Bn,
+                                                              int L, int D) {
+  __shared__ float part[4];
+  __shared__ float extra[2];  // |x_p| of the object row, |new object row|
+  const int lb = blockIdx.x, b = lb % Bn;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pobj = obj.pos ? obj.pos[b] : -1;
+  float s = 0.f;
+  for (int pos = wave; pos < L; pos += 4) {
+    float x[TMAX][8];
+    row_load(last + ((long long)lb * L + pos) * D, D, lane, x);
+    const float nx = sqrtf(row_dot(x, x));
+    s += nx;
+    if (pos == pobj) {
+      float nn = 0.f;
+      if (!obj_unc) {  // constrained object row: x + alpha * b/|b| * |x|
+        float bv[TMAX][8];
+        row_load(obj.b + (long long)lb * D, D, lane, bv);
+        const float f = obj.alpha * nx / sqrtf(row_dot(bv, bv));
+#pragma unroll
+        for (int i = 0; i < TMAX; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bv[i][j] = x[i][j] + f * bv[i][j];
+        nn = sqrtf(row_dot(bv, bv));
+      }
+      if (lane == 0) {
+        extra[0] = nx;
+        extra[1] = nn;
+      }
+    }
+  }
+  if (lane == 0) part[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float S = part[0] + part[1] + part[2] + part[3];
+    const float mo = S / (float)L;
+    nterm[lb] = mo;
+    float mv = mo;
+    if (pobj >= 0) mv = (S - extra[0] + (obj_unc ? mo : extra[1])) / (float)L;
+    nterm[nl * Bn + lb] = mv;
+  }
+}
 
 __global__ __launch_bounds__(256) void text_final_fwd_kernel(const float* __restrict__ last,
                                                              const float* __restrict__ gamma,
@@ -430,12 +485,20 @@ __global__ __launch_bounds__(256) void text_final_fwd_kernel(const float* __rest
     if (a.pos && a.pos[b] == pos) {
       float bv[TMAX][8];
       row_load(a.b + ((long long)l * Bn + b) * D, D, lane, bv);
-      const float nb = sqrtf(row_dot(bv, bv)), nx = sqrtf(row_dot(x, x));
-      const float f = a.alpha * nx / nb;
+      const float nb = sqrtf(row_dot(bv, bv));
+      if (a.nterm) {  // unconstrained: the row is replaced by b/|b| * detach(mean_j |x_j|)
+        const float f = a.nterm[l * Bn + b] / nb;
 #pragma unroll
-      for (int i = 0; i < TMAX; ++i)
+        for (int i = 0; i < TMAX; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[i][j] += f * bv[i][j];
+          for (int j = 0; j < 8; ++j) x[i][j] = f * bv[i][j];
+      } else {
+        const float f = a.alpha * sqrtf(row_dot(x, x)) / nb;
+#pragma unroll
+        for (int i = 0; i < TMAX; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[i][j] += f * bv[i][j];
+      }
       changed = true;
     }
   }
@@ -470,14 +533,16 @@ __global__ __launch_bounds__(256) void text_final_bwd_kernel(const float* __rest
     float bv[TMAX][8], nw[TMAX][8];
     row_load(a.b + ((long long)l * Bn + b) * D, D, lane, bv);
     const float nb = sqrtf(row_dot(bv, bv)), nx = sqrtf(row_dot(x, x));
-    const float f = a.alpha * nx / nb;
+    const bool unc = a.nterm != nullptr;
+    const float f = unc ? a.nterm[l * Bn + b] / nb : a.alpha * nx / nb;
 #pragma unroll
     for (int i = 0; i < TMAX; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) nw[i][j] = x[i][j] + f * bv[i][j];
+      for (int j = 0; j < 8; ++j) nw[i][j] = (unc ? 0.f : x[i][j]) + f * bv[i][j];
     float g[TMAX][8];
     row_ln_bwd(nw, dctx_v + row * D, D, lane, eps, gamma, g);
-    // new = x + alpha * u * |x|, u = b/|b|:  dx = g + alpha (u.g) x/|x| ;  db = alpha |x|/|b| (g - u (u.g))
+    // constrained:   new = x + alpha * u * |x|, u = b/|b|:  dx = g + alpha (u.g) x/|x| ;  db = alpha |x|/|b| (g - u (u.g))
+    // unconstrained: new = m * u with m detached:           dx = 0                     ;  db = m/|b| (g - u (u.g))
     const float ug = row_dot(bv, g) / nb;
     float* dbp = a.db + ((long long)l * Bn + b) * D;
 #pragma unroll
@@ -485,7 +550,7 @@ __global__ __launch_bounds__(256) void text_final_bwd_kernel(const float* __rest
       int c = lane + 64 * i;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        g2[i][j] = g[i][j] + a.alpha * ug * x[i][j] / nx;
+        g2[i][j] = unc ? 0.f : g[i][j] + a.alpha * ug * x[i][j] / nx;
         if (c * 8 < D) dbp[c * 8 + j] = f * (g[i][j] - bv[i][j] / nb * ug);
       }
     }
@@ -563,7 +628,8 @@ extern "C" long long vneti_mapper_rowgrad_floats(int R, int hidden, int D, int h
   return (long long)R * ((has_bypass ? 2 * D : D) + 4 * hidden);
 }
 
-extern "C" int vneti_mapper_fwd(const float* params, const float* data, int nfeat, const float* w_enc,
+extern "C" int vneti_mapper_fwd(const float* params, const int* slot, long long slot_stride, const float* data,
+                                int nfeat, const float* w_enc,
                                 const float* hidden_mask, float norm_scale, float* word, float* bypass, float* save,
                                 int R, int enc_dim, int hidden, int D, int has_bypass, void* stream) {
   MapperParams mp;
@@ -571,12 +637,13 @@ extern "C" int vneti_mapper_fwd(const float* params, const float* data, int nfea
              enc_dim, hidden, D);
   VN_REQUIRE(params && data && w_enc && word && save && R > 0 && nfeat > 0 && (!has_bypass || bypass),
              "mapper_fwd: bad arguments");
-  hipLaunchKernelGGL(mapper_fwd_kernel, dim3(R), dim3(256), 0, ST, mp, params, data, nfeat, w_enc, hidden_mask,
+  hipLaunchKernelGGL(mapper_fwd_kernel, dim3(R), dim3(256), 0, ST, mp, params, slot, slot_stride, data, nfeat, w_enc, hidden_mask,
                      norm_scale, word, bypass, save);
   return vneti_check_launch("mapper_fwd");
 }
 
-extern "C" int vneti_mapper_bwd(const float* params, const float* hidden_mask, float norm_scale, const float* word,
+extern "C" int vneti_mapper_bwd(const float* params, const int* slot, long long slot_stride,
+                                const float* hidden_mask, float norm_scale, const float* word,
                                 const float* dword_src, const int* dword_rows, long long ld_src,
                                 const float* dbypass, const float* save, float* rowgrads, float* grads,
                                 int accumulate, int R, int enc_dim, int hidden, int D, int has_bypass,
@@ -586,10 +653,10 @@ extern "C" int vneti_mapper_bwd(const float* params, const float* hidden_mask, f
   VN_REQUIRE(np > 0, "mapper_bwd: unsupported dims E=%d hd=%d D=%d", enc_dim, hidden, D);
   VN_REQUIRE(params && word && dword_src && dword_rows && save && rowgrads && grads && R > 0,
              "mapper_bwd: bad arguments");
-  hipLaunchKernelGGL(mapper_bwd_rows_kernel, dim3(R), dim3(256), 0, ST, mp, params, hidden_mask, norm_scale, word,
+  hipLaunchKernelGGL(mapper_bwd_rows_kernel, dim3(R), dim3(256), 0, ST, mp, params, slot, slot_stride, hidden_mask, norm_scale, word,
                      dword_src, dword_rows, ld_src, dbypass, save, rowgrads);
   hipLaunchKernelGGL(mapper_bwd_reduce_kernel, dim3(cdiv(np, 256)), dim3(256), 0, ST, mp, R, save,
-                     (const float*)rowgrads, grads, np, accumulate);
+                     (const float*)rowgrads, grads, np, accumulate, slot, slot_stride);
   return vneti_check_launch("mapper_bwd");
 }
 
@@ -606,11 +673,18 @@ extern "C" int vneti_text_embed(const float* tok_emb, const float* pos_emb, cons
 
 extern "C" int vneti_text_final_fwd(const float* last, const float* gamma, const float* beta, float eps,
                                     const int* pos_obj, const float* bypass_obj, float alpha_obj,
-                                    const int* pos_view, const float* bypass_view, float alpha_view, void* ctx_k,
+                                    int unconstrained_obj, const int* pos_view, const float* bypass_view,
+                                    float alpha_view, int unconstrained_view, float* norm_terms, void* ctx_k,
                                     void* ctx_v, int nl, int Bn, int L, int D, void* stream) {
   VN_REQUIRE(last && gamma && beta && ctx_k && ctx_v && D % 8 == 0 && D <= 8 * 64 * TMAX, "text_final_fwd: bad arguments");
-  BypassArgs o{pos_obj && bypass_obj ? pos_obj : nullptr, bypass_obj, nullptr, alpha_obj};
-  BypassArgs v{pos_view && bypass_view ? pos_view : nullptr, bypass_view, nullptr, alpha_view};
+  const bool uo = unconstrained_obj && pos_obj && bypass_obj, uv = unconstrained_view && pos_view && bypass_view;
+  VN_REQUIRE(!(uo || uv) || norm_terms, "text_final_fwd: unconstrained bypass needs norm_terms[2*nl*B]");
+  BypassArgs o{pos_obj && bypass_obj ? pos_obj : nullptr, bypass_obj, nullptr, alpha_obj, uo ? norm_terms : nullptr};
+  BypassArgs v{pos_view && bypass_view ? pos_view : nullptr, bypass_view, nullptr, alpha_view,
+               uv ? norm_terms + (long long)nl * Bn : nullptr};
+  if (uo || uv)
+    hipLaunchKernelGGL(text_norm_terms_kernel, dim3(nl * Bn), dim3(256), 0, ST, last, o, uo ? 1 : 0, norm_terms, nl,
+                       Bn, L, D);
   long long rows = (long long)nl * Bn * L;
   hipLaunchKernelGGL(text_final_fwd_kernel, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, ST, last, gamma, beta, eps, o,
                      v, (half_t*)ctx_k, (half_t*)ctx_v, nl, Bn, L, D);
@@ -618,15 +692,19 @@ extern "C" int vneti_text_final_fwd(const float* last, const float* gamma, const
 }
 
 extern "C" int vneti_text_final_bwd(const float* last, const float* gamma, float eps, const int* pos_obj,
-                                    const float* bypass_obj, float alpha_obj, float* dbypass_obj,
-                                    const int* pos_view, const float* bypass_view, float alpha_view,
-                                    float* dbypass_view, const void* dctx_k, const void* dctx_v, float* dX, int nl,
-                                    int Bn, int L, int D, void* stream) {
+                                    const float* bypass_obj, float alpha_obj, int unconstrained_obj,
+                                    float* dbypass_obj, const int* pos_view, const float* bypass_view,
+                                    float alpha_view, int unconstrained_view, float* dbypass_view,
+                                    const float* norm_terms, const void* dctx_k, const void* dctx_v, float* dX,
+                                    int nl, int Bn, int L, int D, void* stream) {
   VN_REQUIRE(last && gamma && dctx_k && dctx_v && dX && D % 8 == 0 && D <= 8 * 64 * TMAX, "text_final_bwd: bad arguments");
   VN_REQUIRE(!(pos_obj && bypass_obj && !dbypass_obj) && !(pos_view && bypass_view && !dbypass_view),
              "text_final_bwd: missing bypass gradient buffer");
-  BypassArgs o{pos_obj && bypass_obj ? pos_obj : nullptr, bypass_obj, dbypass_obj, alpha_obj};
-  BypassArgs v{pos_view && bypass_view ? pos_view : nullptr, bypass_view, dbypass_view, alpha_view};
+  const bool uo = unconstrained_obj && pos_obj && bypass_obj, uv = unconstrained_view && pos_view && bypass_view;
+  VN_REQUIRE(!(uo || uv) || norm_terms, "text_final_bwd: unconstrained bypass needs the forward's norm_terms");
+  BypassArgs o{pos_obj && bypass_obj ? pos_obj : nullptr, bypass_obj, dbypass_obj, alpha_obj, uo ? norm_terms : nullptr};
+  BypassArgs v{pos_view && bypass_view ? pos_view : nullptr, bypass_view, dbypass_view, alpha_view,
+               uv ? norm_terms + (long long)nl * Bn : nullptr};
   long long rows = (long long)nl * Bn * L;
   hipLaunchKernelGGL(text_final_bwd_kernel, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, ST, last, gamma, eps, o, v,
                      (const half_t*)dctx_k, (const half_t*)dctx_v, dX, nl, Bn, L, D);

@@ -42,6 +42,7 @@ class Schedule:
         self.eps = eps
         self.dev = device
         self.need_backward = need_backward
+        self.fwd_pre: List = []  # launches that do not depend on the schedule's main input (may run early)
         self.fwd: List = []
         self.bwd: List = []
         self.tape: List = []
@@ -51,7 +52,9 @@ class Schedule:
         self.temb_all = None
         # vneti_groupnorm_ws_floats upper bound: <=256 slabs x 2G partials + 2*B*G finals
         self.gn_ws = self._buf((batch * 256 * 2 * groups + 2 * batch * groups,), torch.float32)
-        # shared f32 scratch for split-K GEMM partials (all schedules run on one stream)
+        # f32 scratch for split-K GEMM / q-split attention partials: one per schedule, so two schedules
+        # may run concurrently on different streams (bind_workspace() pins it into every launch)
+        self.ws = self._buf((16 * 2 ** 20,), torch.float32)
         if ops._default_ws is None or ops._default_ws.device != torch.device(device, torch.cuda.current_device()):
             ops.set_default_gemm_workspace(torch.empty(16 * 2 ** 20, dtype=torch.float32, device=device))
 
@@ -131,7 +134,7 @@ class Schedule:
         if not torch.cuda.is_available():
             return
         cache = Schedule._tile_cache
-        for lst in (self.fwd, self.bwd):
+        for lst in (self.fwd_pre, self.fwd, self.bwd):
             for idx, f in enumerate(lst):
                 if getattr(f, "func", None) is not ops.gemm or f.keywords.get("tile_hint"):
                     continue
@@ -155,6 +158,16 @@ class Schedule:
                 kw = dict(f.keywords)
                 kw["tile_hint"] = cache[key]
                 lst[idx] = partial(ops.gemm, *f.args, **kw)
+
+    def bind_workspace(self):
+        """pin this schedule's own split-K / q-split scratch into every launch that may use one."""
+        for lst in (self.fwd_pre, self.fwd, self.bwd):
+            for idx, f in enumerate(lst):
+                fn = getattr(f, "func", None)
+                if fn is ops.gemm or fn is ops.attn_bwd_dkv:
+                    kw = dict(f.keywords)
+                    kw["workspace"] = self.ws
+                    lst[idx] = partial(fn, *f.args, **kw)
 
     # ------------------------------------------------------------------ layer builders
     def _gn(self, x: T, name, w, eps, silu):
@@ -269,9 +282,17 @@ class Schedule:
         self._contrib_gemm(x, out.g, r["wd_"], M=x.rows, conv=desc)
 
     # ------------------------------------------------------------------ execution
-    def forward(self):
+    def forward_pre(self):
+        for f in self.fwd_pre:
+            f()
+
+    def forward_main(self):
         for f in self.fwd:
             f()
+
+    def forward(self):
+        self.forward_pre()
+        self.forward_main()
 
     def backward(self):
         for f in self.bwd:

@@ -46,7 +46,12 @@ class TrainStepEngine:
                  n_view_params: int = 12, lr: float = 1e-3, betas=(0.9, 0.999), adam_eps: float = 1e-8,
                  weight_decay: float = 1e-2, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  seed: int = 0, world_size: int = 1, device_rng: bool = True, device: str = "cuda",
-                 need_backward: bool = True, grad_accum: int = 1):
+                 need_backward: bool = True, grad_accum: int = 1, overlap: bool = True,
+                 unconstrained_object: bool = False, unconstrained_view: bool = False,
+                 nested_dropout_prob: float = 0.0, hidden_object: int = 64):
+        """mapper_object: one mapper state_dict, or a list of them (learnable_mode 3: one object mapper per
+        scene, `mapper_object_lookup`, training/coach.py:505-552) — `set_batch(object_index=k)` picks the one
+        the batch trains."""
         from .text import flatten_mapper_state
         self.cfg = cfg
         self.B, self.H, self.W = batch, height, width
@@ -58,27 +63,43 @@ class TrainStepEngine:
         self.h, self.w = height >> (nlev - 1), width >> (nlev - 1)
         Lc = cfg.vae.latent_channels
         D = cfg.clip.hidden_size
-        # ---- trainable state: one flat f32 bucket (object mapper [+ view mapper]) ----
-        flat_o = flatten_mapper_state(mapper_object)
+        # ---- trainable state: one flat f32 bucket [object mapper 0 .. K-1 | view mapper] ----
+        objs = list(mapper_object) if isinstance(mapper_object, (list, tuple)) else [mapper_object]
+        flats = [flatten_mapper_state(sd) for sd in objs]
+        self.n_objects = len(flats)
+        self.n_obj = flats[0].numel()  # floats per object mapper
+        assert all(f.numel() == self.n_obj for f in flats), "object mappers must share one architecture"
         flat_v = flatten_mapper_state(mapper_view) if (mapper_view is not None and train_view) else None
-        n = flat_o.numel() + (flat_v.numel() if flat_v is not None else 0)
+        n_all_obj = self.n_obj * self.n_objects
+        n = n_all_obj + (flat_v.numel() if flat_v is not None else 0)
         self.params = torch.zeros(n, dtype=torch.float32, device=device)
-        self.params[: flat_o.numel()].copy_(flat_o)
+        self.params[:n_all_obj].copy_(torch.cat(flats))
         if flat_v is not None:
-            self.params[flat_o.numel():].copy_(flat_v)
+            self.params[n_all_obj:].copy_(flat_v)
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
-        self.n_obj = flat_o.numel()
-        mo = MapperState(self.params[: self.n_obj], w_enc_object.to(device).float().contiguous(), norm_scale_object,
-                         alpha_object)
+        self.n_all_obj = n_all_obj
+        # device-side choice of the object mapper (graph-replay safe) + torch's per-parameter Adam step counts
+        self.obj_slot = torch.zeros(1, dtype=torch.int32, device=device)
+        self.seg_step = torch.zeros(self.n_objects, dtype=torch.int32, device=device)
+        self.active_object = 0
+        multi = self.n_objects > 1
+        # RNG state first: nested dropout draws from it
+        self.rng_state = torch.tensor([seed & 0x7FFFFFFF, 0], dtype=torch.int32, device=device)
+        mo = MapperState(self.params[:n_all_obj], w_enc_object.to(device).float().contiguous(), norm_scale_object,
+                         alpha_object, hidden=hidden_object, unconstrained=unconstrained_object,
+                         nested_dropout_prob=nested_dropout_prob, slot=self.obj_slot if multi else None,
+                         slot_stride=self.n_obj if multi else 0)
         mv, gv = None, None
         if mapper_view is not None:
             if flat_v is not None:
-                pv, gv = self.params[self.n_obj:], self.grads[self.n_obj:]
+                pv, gv = self.params[n_all_obj:], self.grads[n_all_obj:]
             else:  # frozen pretrained view mapper (learnable_mode 4/5)
                 pv = flatten_mapper_state(mapper_view).to(device)
-            mv = MapperState(pv, w_enc_view.to(device).float().contiguous(), norm_scale_view, alpha_view)
+            mv = MapperState(pv, w_enc_view.to(device).float().contiguous(), norm_scale_view, alpha_view,
+                             unconstrained=unconstrained_view,
+                             nested_dropout_prob=nested_dropout_prob if flat_v is not None else 0.0)
         # ---- device-resident scalars ----
         self.grad_accum = grad_accum
         # accelerate scales each micro-loss by 1/accum and DDP averages over ranks: fold both into AdamW
@@ -86,15 +107,14 @@ class TrainStepEngine:
                                   dtype=torch.float32, device=device)
         self.scaler = torch.tensor([loss_scale, 0.0, 0.0], dtype=torch.float32, device=device)
         self.opt_step = torch.zeros(1, dtype=torch.int32, device=device)
-        self.rng_state = torch.tensor([seed & 0x7FFFFFFF, 0], dtype=torch.int32, device=device)
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
         self.ac = alphas_cumprod(cfg.ddpm).to(device)
         # ---- engines ----
         self.unet = UNetEngine(cfg.unet, unet_w, batch, self.h, self.w, cfg.clip.max_positions, device, need_backward)
         self.vae = VAEEncoderEngine(cfg.vae, vae_w, batch, height, width, device)
         self.text = TextEngine(cfg.clip, clip_w, cfg.unet.n_cross_layers, batch, self.unet.timesteps, self.unet.ctx_k,
-                               self.unet.ctx_v, self.unet.dctx_k, self.unet.dctx_v, mo, self.grads[: self.n_obj], mv,
-                               gv, n_view_params, train_view, device, need_backward)
+                               self.unet.ctx_v, self.unet.dctx_k, self.unet.dctx_v, mo, self.grads[:n_all_obj], mv,
+                               gv, n_view_params, train_view, device, need_backward, rng_state=self.rng_state)
         self.timesteps = self.unet.timesteps
         self.pixel_values = self.vae.x_in
         shape = (batch, Lc, self.h, self.w)
@@ -103,14 +123,37 @@ class TrainStepEngine:
         self.latents = torch.zeros(shape, dtype=torch.float32, device=device)
         self.target = torch.zeros(shape, dtype=torch.float32, device=device)
         self.need_backward = need_backward
+        self.overlap = overlap
+        self.side = torch.cuda.Stream() if overlap else None
         self.graph_a = self.graph_b = self.graph_acc = None
         self.micro = 0
         self.n_loss = batch * Lc * self.h * self.w
 
     # ------------------------------------------------------------------ inputs
-    def set_batch(self, pixel_values, input_ids, placeholder_object, placeholder_view=None, view_params=None):
+    def set_batch(self, pixel_values, input_ids, placeholder_object, placeholder_view=None, view_params=None,
+                  object_index: int = 0):
+        """object_index: which object mapper this batch trains (a batch is single-scene:
+        models/net_clip_text_embedding.py:67-76 asserts one placeholder id and looks its mapper up)."""
+        if not 0 <= object_index < self.n_objects:
+            raise ValueError(f"object_index {object_index} out of range (have {self.n_objects} object mappers)")
+        if self.micro != 0 and object_index != self.active_object:
+            raise ValueError("the object mapper may not change inside a gradient-accumulation group")
+        self.active_object = object_index
+        self.obj_slot.fill_(object_index)
         self.pixel_values.copy_(pixel_values, non_blocking=True)
         self.text.set_batch(input_ids, placeholder_object, placeholder_view, view_params)
+
+    def train(self, mode: bool = True):
+        """nested dropout is a training-time feature (neti_mapper.py:403); eval() turns the draws off.
+        (a captured graph keeps the mode it was captured in)"""
+        self.text.training = mode
+        return self
+
+    def object_params(self, k: int = 0) -> torch.Tensor:
+        return self.params[k * self.n_obj:(k + 1) * self.n_obj]
+
+    def view_params_flat(self) -> torch.Tensor:
+        return self.params[self.n_all_obj:]
 
     def set_noise(self, eps, noise, timesteps):
         """host-supplied randomness (parity tests: identical values for the oracle and the GPU)."""
@@ -130,12 +173,24 @@ class TrainStepEngine:
             ops.rng_fill_randint(self.timesteps, self.cfg.ddpm.num_train_timesteps, self.rng_state, 0)
             ops.rng_fill_normal(self.eps, self.rng_state, 1)
             ops.rng_fill_normal(self.noise, self.rng_state, 2)
+        # fork: the 16 mapper+CLIP passes (many small launches) run beside the VAE encoder (few large
+        # ones) on a second stream; each schedule owns its split-K scratch, so they never alias
+        main = torch.cuda.current_stream()
+        if self.overlap:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self.text.forward()
+                self.unet.forward_pre()  # time embedding + the 32 context K/V projections
         self.vae.forward()
         ops.sample_add_noise(self.vae.moments, self.eps, self.noise, self.timesteps, self.ac,
                              self.cfg.vae.scaling_factor, self.cfg.ddpm.prediction_type == "v_prediction", self.latents,
                              self.unet.x_in, self.target, B, Lc, hw)
-        self.text.forward()
-        self.unet.forward()
+        if self.overlap:
+            main.wait_stream(self.side)  # join
+        else:
+            self.text.forward()
+            self.unet.forward_pre()
+        self.unet.forward_main()
         self.loss_sum.zero_()
         ops.mse_loss_grad(self.unet.pred, self.target, self.unet.dpred, self.loss_sum, self.scaler, B, Lc, hw)
         if self.need_backward:
@@ -143,13 +198,36 @@ class TrainStepEngine:
             self.text.backward()
 
     def optimizer_step(self):
-        ops.adamw_flat(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.hyper, self.scaler, self.opt_step,
-                       self.growth_interval)
+        a = (self.hyper, self.scaler, self.opt_step, self.growth_interval)
+        if self.n_objects == 1:
+            ops.adamw_flat(self.params, self.grads, self.exp_avg, self.exp_avg_sq, *a)
+            return
+        # several buckets, one optimizer step: check all, apply all, then GradScaler.update once
+        no = self.n_all_obj
+        obj = (self.params[:no], self.grads[:no], self.exp_avg[:no], self.exp_avg_sq[:no], self.n_obj, self.n_objects,
+               self.seg_step, self.obj_slot)
+        view = (self.params[no:], self.grads[no:], self.exp_avg[no:], self.exp_avg_sq[no:])
+        has_view = self.params.numel() > no
+        if has_view:
+            ops.adamw_flat(*view, *a, phases=ops.OPT_CHECK)
+        ops.adamw_segments(*obj, *a, phases=ops.OPT_CHECK)
+        if has_view:
+            ops.adamw_flat(*view, *a, phases=ops.OPT_APPLY)
+        ops.adamw_segments(*obj, *a, phases=ops.OPT_APPLY | ops.OPT_FINISH)
 
     def all_reduce(self):
+        """the one exchange step of data-parallel training: sum the mapper gradients over ranks
+        (the 1/world_size is folded into AdamW).  With several object mappers every rank trains the
+        same scene per step (same scene-sampler seed), so only that segment and the view mapper move."""
         if self.world_size > 1:
             from ..parallel import all_reduce_sum_
-            all_reduce_sum_(self.grads)
+            if self.n_objects == 1:
+                all_reduce_sum_(self.grads)
+            else:
+                k = self.active_object
+                all_reduce_sum_(self.grads[k * self.n_obj:(k + 1) * self.n_obj])
+                if self.grads.numel() > self.n_all_obj:
+                    all_reduce_sum_(self.grads[self.n_all_obj:])
 
     def step_eager(self):
         """one micro-step; the optimizer runs after every `grad_accum`-th micro-step."""
@@ -167,8 +245,8 @@ class TrainStepEngine:
         """Capture the step into hipGraphs: [forward+backward] and [optimizer], with the RCCL
         all-reduce of the flat gradient bucket between them (single graph when world_size == 1)."""
         # the warm-up launches below are real steps: snapshot the trainable / RNG state and put it back
-        state = [t.clone() for t in (self.params, self.exp_avg, self.exp_avg_sq, self.opt_step, self.scaler,
-                                     self.rng_state)]
+        saved = (self.params, self.exp_avg, self.exp_avg_sq, self.opt_step, self.scaler, self.rng_state, self.seg_step)
+        state = [t.clone() for t in saved]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -191,8 +269,7 @@ class TrainStepEngine:
                     self.optimizer_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        for dst, src in zip((self.params, self.exp_avg, self.exp_avg_sq, self.opt_step, self.scaler, self.rng_state),
-                            state):
+        for dst, src in zip(saved, state):
             dst.copy_(src)
         self.micro = 0
 
@@ -216,7 +293,7 @@ class TrainStepEngine:
 
     # ------------------------------------------------------------------ introspection
     def launches(self) -> List:
-        out = list(self.vae.fwd) + list(self.text.fwd) + list(self.unet.fwd)
+        out = list(self.vae.fwd) + list(self.text.fwd) + list(self.unet.fwd_pre) + list(self.unet.fwd)
         if self.need_backward:
             out += list(self.unet.bwd) + list(self.text.bwd)
         return out

@@ -30,13 +30,18 @@ class MapperState:
     """Flat f32 parameter bucket of one NeTIMapper (arch_view_net=15) + its Fourier frequencies."""
 
     def __init__(self, params: torch.Tensor, w_enc: torch.Tensor, norm_scale: Optional[float], alpha: float,
-                 hidden: int = 64, enc_dim: int = 64):
-        self.params = params
+                 hidden: int = 64, enc_dim: int = 64, unconstrained: bool = False, nested_dropout_prob: float = 0.0,
+                 slot: Optional[torch.Tensor] = None, slot_stride: int = 0):
+        self.params = params            # flat bucket (of `slot_stride`-spaced mappers when slot is given)
         self.w_enc = w_enc
         self.norm_scale = norm_scale
         self.alpha = alpha
         self.hidden = hidden
         self.enc_dim = enc_dim
+        self.unconstrained = unconstrained              # bypass_unconstrained (neti_mapper.py:130)
+        self.nested_dropout_prob = nested_dropout_prob  # 0 disables (use_nested_dropout=False)
+        self.slot = slot                # device int32[1]: which mapper of the bucket (mapper_object_lookup)
+        self.slot_stride = slot_stride
 
 
 def flatten_mapper_state(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -69,7 +74,7 @@ class TextEngine(Schedule):
                  dctx_v: torch.Tensor, mapper_object: MapperState, grads_object: torch.Tensor,
                  mapper_view: Optional[MapperState] = None, grads_view: Optional[torch.Tensor] = None,
                  n_view_params: int = 12, train_view: bool = True, device: str = "cuda",
-                 need_backward: bool = True, autotune: bool = True):
+                 need_backward: bool = True, autotune: bool = True, rng_state: Optional[torch.Tensor] = None):
         super().__init__(batch, 32, cfg.eps, device, need_backward)
         self.cfg = cfg
         self.nl = n_layers
@@ -90,7 +95,13 @@ class TextEngine(Schedule):
         self.pos_view = torch.full((B,), -1, dtype=torch.int32, device=device) if mapper_view else None
         self.rows_view = torch.zeros((self.R,), dtype=torch.int32, device=device) if mapper_view else None
         self.view_params = self._buf((B, n_view_params), torch.float32, zero=True) if mapper_view else None
-        self.hidden_mask_obj = None  # nested dropout masks may be installed by the trainer
+        # nested dropout (neti_mapper.py:401-414): 0/1 masks over the mappers' hidden vectors, redrawn every
+        # step from the device RNG while `training`; None = feature off
+        self.rng_state = rng_state
+        self.training = True
+        self.hidden_mask_obj = self._mask_buf(mapper_object)
+        self.hidden_mask_view = self._mask_buf(mapper_view) if mapper_view is not None else None
+        self.norm_terms = self._buf((2, self.R), torch.float32, zero=True)
         self.accumulate_grads = False  # True on micro-steps 2..k of a gradient-accumulation group
         self.tok_emb = self._w32(weights["text_model.embeddings.token_embedding.weight"])
         self.pos_emb = self._w32(weights["text_model.embeddings.position_embedding.weight"])
@@ -99,6 +110,23 @@ class TextEngine(Schedule):
             self._build_backward()
         if autotune:
             self.autotune()
+        self.bind_workspace()
+
+    def _mask_buf(self, m: MapperState):
+        if m.nested_dropout_prob <= 0.0:
+            return None
+        if self.rng_state is None:
+            raise ValueError("nested dropout needs the step engine's device RNG state")
+        return torch.ones((self.R, m.hidden), dtype=torch.float32, device=self.dev)
+
+    def _draw_masks(self):
+        for mask, m, sid in ((self.hidden_mask_obj, self.mo, 3), (self.hidden_mask_view, self.mv, 4)):
+            if mask is None:
+                continue
+            if self.training:
+                ops.nested_dropout_mask(mask, self.nl, self.B, m.hidden, m.nested_dropout_prob, self.rng_state, sid)
+            else:
+                mask.fill_(1.0)  # eval: no dropout (truncation_idx is an inference-only knob)
 
     # ------------------------------------------------------------------ batch plumbing
     def set_batch(self, input_ids: torch.Tensor, placeholder_object: torch.Tensor,
@@ -147,17 +175,20 @@ class TextEngine(Schedule):
         f = self.fwd
         mo = self.mo
         self.bo = self._mapper_bufs(mo, 2)
+        if self.hidden_mask_obj is not None or self.hidden_mask_view is not None:
+            f.append(self._draw_masks)
         f.append(partial(ops.mapper_inputs, self.timesteps, None, self.bo["data"], nl, B))
         f.append(lambda: ops.mapper_fwd(mo.params, self.bo["data"], mo.w_enc, self.hidden_mask_obj, mo.norm_scale,
                                         self.bo["word"], self.bo["byp"], self.bo["save"], R, mo.enc_dim, mo.hidden, D,
-                                        True))
+                                        True, mo.slot, mo.slot_stride))
         self.bv = None
         if self.mv is not None:
             mv = self.mv
             self.bv = self._mapper_bufs(mv, 2 + self.view_params.shape[1])
             f.append(partial(ops.mapper_inputs, self.timesteps, self.view_params, self.bv["data"], nl, B))
-            f.append(partial(ops.mapper_fwd, mv.params, self.bv["data"], mv.w_enc, None, mv.norm_scale,
-                             self.bv["word"], self.bv["byp"], self.bv["save"], R, mv.enc_dim, mv.hidden, D, True))
+            f.append(partial(ops.mapper_fwd, mv.params, self.bv["data"], mv.w_enc, self.hidden_mask_view,
+                             mv.norm_scale, self.bv["word"], self.bv["byp"], self.bv["save"], R, mv.enc_dim, mv.hidden,
+                             D, True))
         x = self._buf((Rt, D), torch.float32)
         f.append(partial(ops.text_embed, self.tok_emb, self.pos_emb, self.ids, self.pos_obj, self.bo["word"],
                          self.pos_view, self.bv["word"] if self.bv else None, x, nl, B, L, D))
@@ -206,7 +237,9 @@ class TextEngine(Schedule):
         self.fln_b = self._w32(w["text_model.final_layer_norm.bias"])
         f.append(lambda: ops.text_final_fwd(self.last, self.fln_g, self.fln_b, cfg.eps, self.pos_obj, self.bo["byp"],
                                             self.mo.alpha, self.pos_view, self.bv["byp"] if self.bv else None,
-                                            self.mv.alpha if self.mv else 0.0, self.ctx_k, self.ctx_v, nl, B, L, D))
+                                            self.mv.alpha if self.mv else 0.0, self.ctx_k, self.ctx_v, nl, B, L, D,
+                                            self.mo.unconstrained, bool(self.mv and self.mv.unconstrained),
+                                            self.norm_terms))
 
     def _build_backward(self):
         cfg = self.cfg
@@ -220,7 +253,8 @@ class TextEngine(Schedule):
                                              self.mo.alpha, self.bo["dbyp"], self.pos_view,
                                              self.bv["byp"] if self.bv else None, self.mv.alpha if self.mv else 0.0,
                                              self.bv["dbyp"] if self.bv else None, self.dctx_k, self.dctx_v, dx, nl, B,
-                                             L, D))
+                                             L, D, self.mo.unconstrained, bool(self.mv and self.mv.unconstrained),
+                                             self.norm_terms))
         g16 = self._buf((Rt, D))
         dxm = self._buf((Rt, D), torch.float32)
         for r in reversed(self.layers):
@@ -259,9 +293,10 @@ class TextEngine(Schedule):
         mo = self.mo
         bw.append(lambda: ops.mapper_bwd(mo.params, self.hidden_mask_obj, mo.norm_scale, self.bo["word"], self.dx0,
                                          self.rows_obj, D, self.bo["dbyp"], self.bo["save"], self.bo["rowg"], self.go,
-                                         self.accumulate_grads, R, mo.enc_dim, mo.hidden, D, True))
+                                         self.accumulate_grads, R, mo.enc_dim, mo.hidden, D, True, mo.slot,
+                                         mo.slot_stride))
         if self.train_view:
             mv = self.mv
-            bw.append(lambda: ops.mapper_bwd(mv.params, None, mv.norm_scale, self.bv["word"], self.dx0,
+            bw.append(lambda: ops.mapper_bwd(mv.params, self.hidden_mask_view, mv.norm_scale, self.bv["word"], self.dx0,
                                              self.rows_view, D, self.bv["dbyp"], self.bv["save"], self.bv["rowg"],
                                              self.gv, self.accumulate_grads, R, mv.enc_dim, mv.hidden, D, True))

@@ -52,6 +52,7 @@ class UNetEngine(Schedule):
             self._build_backward()
         if autotune:
             self.autotune()
+        self.bind_workspace()
 
     # ------------------------------------------------------------------ time embedding
     def _pack_time_weights(self, w):
@@ -79,7 +80,7 @@ class UNetEngine(Schedule):
         self.temb_all = self._buf((self.B, self.temb_total))
 
     def _time_ops(self):
-        f = self.fwd
+        f = self.fwd_pre  # depends on the timesteps only
         f.append(partial(ops.timestep_embedding, self.timesteps, self.t_sin))
         f.append(partial(ops.gemm, self.t_sin, self.w_t1, self.t_h, bias=self.b_t1, act=ops.ACT_SILU, tile_hint=3))
         # every consumer applies SiLU to temb first (ResnetBlock2D), so store SiLU(temb) directly
@@ -125,11 +126,12 @@ class UNetEngine(Schedule):
         k2 = self._buf((B * L, Cc))
         v2 = self._buf((B * L, Cc))
         self.fwd.append(partial(ops.gemm, n2, r["wq2"], q2))
-        self.fwd.append(partial(ops.gemm, self.ctx_k[layer_idx], r["wk2"], k2))
-        self.fwd.append(partial(ops.gemm, self.ctx_v[layer_idx], r["wv2"], v2))
+        # K/V of the XTI contexts depend only on the text side: prologue launches (overlappable)
+        self.fwd_pre.append(partial(ops.gemm, self.ctx_k[layer_idx], r["wk2"], k2))
+        self.fwd_pre.append(partial(ops.gemm, self.ctx_v[layer_idx], r["wv2"], v2))
         ldl = _rup(L, 8)
         v2t = self._buf((B, Cc, ldl))
-        self.fwd.append(partial(ops.transpose, v2, v2t, L, Cc, B, Cc, L * Cc, ldl, Cc * ldl))
+        self.fwd_pre.append(partial(ops.transpose, v2, v2t, L, Cc, B, Cc, L * Cc, ldl, Cc * ldl))
         o2 = self._buf((M, Cc))
         lse2 = self._buf((B, heads, N), torch.float32)
         self.fwd.append(partial(ops.attn_fwd, q2, k2, v2t, o2, lse2, B, heads, N, L, D, scale, False, ldl))

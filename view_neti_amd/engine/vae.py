@@ -38,6 +38,7 @@ class VAEEncoderEngine(Schedule):
         self._build(weights)
         if autotune:
             self.autotune()
+        self.bind_workspace()
 
     def _build(self, w):
         cfg = self.cfg

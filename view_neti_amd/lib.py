@@ -137,15 +137,18 @@ SIGNATURES = {
     "sample_add_noise": [c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                          c_vp],
     "mse_loss_grad": [c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_int, c_int, c_int, c_vp],
-    "adamw_flat": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_vp],
-    "mapper_fwd": [c_vp, c_vp, c_int, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
-    "mapper_bwd": [c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                   c_int, c_int, c_vp],
+    "adamw_flat": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, c_vp],
+    "adamw_segments": [c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp],
+    "nested_dropout_mask": [c_vp, c_int, c_int, c_int, c_f, c_vp, C.c_uint, c_vp],
+    "mapper_fwd": [c_vp, c_vp, c_ll, c_vp, c_int, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                   c_int, c_vp],
+    "mapper_bwd": [c_vp, c_vp, c_ll, c_vp, c_f, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                   c_int, c_int, c_int, c_int, c_vp],
     "text_embed": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
-    "text_final_fwd": [c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp, c_vp, c_int, c_int, c_int,
-                       c_int, c_vp],
-    "text_final_bwd": [c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp, c_int,
-                       c_int, c_int, c_int, c_vp],
+    "text_final_fwd": [c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp,
+                       c_int, c_int, c_int, c_int, c_vp],
+    "text_final_bwd": [c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp,
+                       c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "cast_f32_f16": [c_vp, c_vp, c_ll, c_vp],
     "mapper_inputs": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp],
 }

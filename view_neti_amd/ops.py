@@ -138,10 +138,12 @@ def attn_bwd_dq(Q, K, Kt, ldkt, V, dO, lse, delta, dQ, Bn, H, Nq, Nk, D, scale, 
             _p(lse), _p(delta), _p(dQ), _ld(dQ), Bn, H, Nq, Nk, D, scale, 1 if causal else 0, stream())
 
 
-def attn_bwd_dkv(Q, Qt, ldqt, K, V, dO, dOt, lddot, lse, delta, dK, dV, Bn, H, Nq, Nk, D, scale, causal):
+def attn_bwd_dkv(Q, Qt, ldqt, K, V, dO, dOt, lddot, lse, delta, dK, dV, Bn, H, Nq, Nk, D, scale, causal,
+                 workspace=None):
+    ws = workspace if workspace is not None else _default_ws
     _l.call("attn_bwd_dkv", _p(Q), _ld(Q), _p(Qt), ldqt, _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO),
             _p(dOt), lddot, _p(lse), _p(delta), _p(dK), _ld(dK), _p(dV), _ld(dV), Bn, H, Nq, Nk, D, scale,
-            1 if causal else 0, _p(_default_ws), _default_ws.numel() if _default_ws is not None else 0, stream())
+            1 if causal else 0, _p(ws), ws.numel() if ws is not None else 0, stream())
 
 
 def softmax_rows(x, rows, cols):
@@ -202,9 +204,22 @@ def mse_loss_grad(pred, target, dpred, loss_sum, loss_scale, Bn, Lc, HW):
             Bn, Lc, HW, stream())
 
 
-def adamw_flat(p, g, m, v, hyper, scaler, step, growth_interval=2000):
+OPT_CHECK, OPT_APPLY, OPT_FINISH, OPT_ALL = 1, 2, 4, 7
+
+
+def adamw_flat(p, g, m, v, hyper, scaler, step, growth_interval=2000, phases=OPT_ALL):
     _l.call("adamw_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(scaler), _p(step), growth_interval,
-            stream())
+            phases, stream())
+
+
+def adamw_segments(p, g, m, v, seg_len, n_seg, seg_step, active, hyper, scaler, step, growth_interval=2000,
+                   phases=OPT_ALL):
+    _l.call("adamw_segments", _p(p), _p(g), _p(m), _p(v), seg_len, n_seg, _p(seg_step), _p(active), active.numel(),
+            _p(hyper), _p(scaler), _p(step), growth_interval, phases, stream())
+
+
+def nested_dropout_mask(mask, nl, Bn, hidden, prob, state, stream_id):
+    _l.call("nested_dropout_mask", _p(mask), nl, Bn, hidden, prob, _p(state), stream_id, stream())
 
 
 def mapper_num_params(enc_dim, hidden, D, has_bypass=True):
@@ -219,15 +234,16 @@ def mapper_rowgrad_floats(R, hidden, D, has_bypass=True):
     return _l.call_ll("mapper_rowgrad_floats", R, hidden, D, 1 if has_bypass else 0)
 
 
-def mapper_fwd(params, data, w_enc, hidden_mask, norm_scale, word, bypass, save, R, enc_dim, hidden, D, has_bypass):
-    _l.call("mapper_fwd", _p(params), _p(data), data.shape[1], _p(w_enc), _p(hidden_mask),
+def mapper_fwd(params, data, w_enc, hidden_mask, norm_scale, word, bypass, save, R, enc_dim, hidden, D, has_bypass,
+               slot=None, slot_stride=0):
+    _l.call("mapper_fwd", _p(params), _p(slot), slot_stride, _p(data), data.shape[1], _p(w_enc), _p(hidden_mask),
             norm_scale if norm_scale is not None else -1.0, _p(word), _p(bypass), _p(save), R, enc_dim, hidden, D,
             1 if has_bypass else 0, stream())
 
 
 def mapper_bwd(params, hidden_mask, norm_scale, word, dword_src, dword_rows, ld_src, dbypass, save, rowgrads, grads,
-               accumulate, R, enc_dim, hidden, D, has_bypass):
-    _l.call("mapper_bwd", _p(params), _p(hidden_mask), norm_scale if norm_scale is not None else -1.0, _p(word),
+               accumulate, R, enc_dim, hidden, D, has_bypass, slot=None, slot_stride=0):
+    _l.call("mapper_bwd", _p(params), _p(slot), slot_stride, _p(hidden_mask), norm_scale if norm_scale is not None else -1.0, _p(word),
             _p(dword_src), _p(dword_rows), ld_src, _p(dbypass), _p(save), _p(rowgrads), _p(grads),
             1 if accumulate else 0, R, enc_dim, hidden, D, 1 if has_bypass else 0, stream())
 
@@ -238,16 +254,19 @@ def text_embed(tok_emb, pos_emb, ids, pos_obj, word_obj, pos_view, word_view, X,
 
 
 def text_final_fwd(last, gamma, beta, eps, pos_obj, byp_obj, alpha_obj, pos_view, byp_view, alpha_view, ctx_k, ctx_v,
-                   nl, Bn, L, D):
-    _l.call("text_final_fwd", _p(last), _p(gamma), _p(beta), eps, _p(pos_obj), _p(byp_obj), alpha_obj, _p(pos_view),
-            _p(byp_view), alpha_view, _p(ctx_k), _p(ctx_v), nl, Bn, L, D, stream())
+                   nl, Bn, L, D, unconstrained_obj=False, unconstrained_view=False, norm_terms=None):
+    _l.call("text_final_fwd", _p(last), _p(gamma), _p(beta), eps, _p(pos_obj), _p(byp_obj), alpha_obj,
+            1 if unconstrained_obj else 0, _p(pos_view), _p(byp_view), alpha_view, 1 if unconstrained_view else 0,
+            _p(norm_terms), _p(ctx_k), _p(ctx_v), nl, Bn, L, D, stream())
 
 
 def text_final_bwd(last, gamma, eps, pos_obj, byp_obj, alpha_obj, dbyp_obj, pos_view, byp_view, alpha_view, dbyp_view,
-                   dctx_k, dctx_v, dX, nl, Bn, L, D):
-    _l.call("text_final_bwd", _p(last), _p(gamma), eps, _p(pos_obj), _p(byp_obj), alpha_obj, _p(dbyp_obj),
-            _p(pos_view), _p(byp_view), alpha_view, _p(dbyp_view), _p(dctx_k), _p(dctx_v), _p(dX), nl, Bn, L, D,
-            stream())
+                   dctx_k, dctx_v, dX, nl, Bn, L, D, unconstrained_obj=False, unconstrained_view=False,
+                   norm_terms=None):
+    _l.call("text_final_bwd", _p(last), _p(gamma), eps, _p(pos_obj), _p(byp_obj), alpha_obj,
+            1 if unconstrained_obj else 0, _p(dbyp_obj), _p(pos_view), _p(byp_view), alpha_view,
+            1 if unconstrained_view else 0, _p(dbyp_view), _p(norm_terms), _p(dctx_k), _p(dctx_v), _p(dX), nl, Bn, L,
+            D, stream())
 
 
 def cast_f32_f16(x, y):

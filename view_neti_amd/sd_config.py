@@ -106,7 +106,23 @@ def tiny() -> SDConfig:
     )
 
 
-CONFIGS = {"sd15": sd15, "sd21": sd21, "tiny": tiny}
+def tiny21() -> SDConfig:
+    """`tiny` with the SD-2.1 family's structural switches: linear proj_in/out, exact-GELU CLIP,
+    v-prediction target (BASELINE.json configs 3-5 run on SD-2.1 shapes)."""
+    c = tiny()
+    return SDConfig(
+        name="tiny21",
+        unet=UNetConfig(block_out_channels=c.unet.block_out_channels, num_heads=c.unet.num_heads,
+                        cross_attention_dim=c.unet.cross_attention_dim, norm_num_groups=c.unet.norm_num_groups,
+                        use_linear_projection=True),
+        vae=c.vae,
+        clip=CLIPTextConfig(vocab_size=1024, hidden_size=128, num_layers=3, num_heads=2, intermediate_size=256,
+                            act="gelu"),
+        ddpm=DDPMConfig(prediction_type="v_prediction"),
+    )
+
+
+CONFIGS = {"sd15": sd15, "sd21": sd21, "tiny": tiny, "tiny21": tiny21}
 
 
 # ----------------------------------------------------------------------------------------------
