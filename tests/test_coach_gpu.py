@@ -46,3 +46,79 @@ def test_coach_mode0_trains_and_saves(tmp_path):
     assert abs(cfg2.model.target_norm_object - cfg.model.target_norm_object) < 1e-6
     emb = torch.load(out / "learned_embeds-final.bin")
     assert list(emb) == ["<toy>"] and emb["<toy>"].shape == (128,)
+
+
+M3_YAML = """
+learnable_mode: 3
+log: {{exp_name: m3, exp_dir: {out}, save_steps: 3}}
+data: {{train_data_dir: data/dtu/Rectified, train_data_subsets: [scan65, scan125], super_category_object_tokens: [object, object],
+       placeholder_object_tokens: [<skull>, <statue>], placeholder_object_token: <object>, dataloader_num_workers: 0,
+       camera_representation: dtu-12d, dtu_subset: 3, dtu_lighting: 3, dtu_preprocess_key: 0, augmentation_key: 0,
+       resolution: 64}}
+model: {{arch_mlp_hidden_dims: 128, use_nested_dropout: True, nested_dropout_prob: 0.5, word_embedding_dim: 128,
+        arch_view_net: 15, arch_view_disable_tl: False, pe_sigma_exp_key: 2, output_bypass_alpha_view: 5,
+        output_bypass_alpha_object: 5, bypass_unconstrained_view: True}}
+eval: {{validation_seeds: [0, 1], num_validation_images: 2, eval_placeholder_object_tokens: [<skull>]}}
+optim: {{max_train_steps: 6, train_batch_size: 2, gradient_accumulation_steps: 1, mixed_precision: fp16}}
+"""
+
+
+def test_coach_mode3_multi_scene(tmp_path, monkeypatch):
+    """BASELINE config 4 in miniature: two DTU scenes -> two object mappers (hidden 128) + one view mapper,
+    nested dropout on, unconstrained view bypass; every batch is single-scene, the scene changes between
+    optimizer steps, checkpoints hold every mapper."""
+    from view_neti_amd.compat import config as C
+    from view_neti_amd.compat.checkpoint_handler import CheckpointHandler
+    from view_neti_amd.compat.coach import Coach
+    from view_neti_amd.compat.dataset import TextualInversionDataset
+    from view_neti_amd.engine.text import flatten_mapper_state
+    monkeypatch.chdir(tmp_path)
+    cal = tmp_path / "data" / "dtu" / "Calibration" / "cal18"
+    cal.mkdir(parents=True)
+    rng = np.random.RandomState(1)
+    mats = rng.randn(49, 3, 4) * np.array([[1e3, 1e3, 1e3, 1e5]])
+    for i in range(49):
+        np.savetxt(cal / f"pos_{i + 1:03d}.txt", mats[i])
+    names = [TextualInversionDataset.dtu_cam_and_lighting_to_fname(c, "3") for c in range(49)]
+    for scan in ("scan65", "scan125"):
+        d = tmp_path / "data" / "dtu" / "Rectified" / scan
+        d.mkdir(parents=True)
+        for n in names:
+            # DTU frames are 1600x1200 (key 0 pads to 1600x1600, then resizes to 512x512)
+            Image.fromarray(rng.randint(0, 255, (1200, 1600, 3), dtype=np.uint8)).save(d / n)
+    y = tmp_path / "m3.yaml"
+    y.write_text(M3_YAML.format(out=str(tmp_path / "out")))
+    cfg = C.parse(C.RunConfig, ["--config_path", str(y)])
+    cfg.log.exp_dir = cfg.log.exp_dir / cfg.log.exp_name
+    cfg.log.logging_dir = cfg.log.exp_dir / cfg.log.logging_dir
+    torch.manual_seed(cfg.seed)
+    coach = Coach(cfg)
+    eng = coach.engine
+    assert eng.n_objects == 2 and eng.text.mo.hidden == 128 and eng.text.mo.nested_dropout_prob == 0.5
+    assert eng.text.mv.unconstrained and not eng.text.mo.unconstrained
+    scenes = []
+    orig = eng.set_batch
+    def spy(*a, **k):
+        scenes.append(k["object_index"])
+        return orig(*a, **k)
+    eng.set_batch = spy
+    p0 = eng.params.clone()
+    coach.train()
+    assert eng.opt_step.item() == 6 and len(scenes) == 6
+    assert set(scenes) == {0, 1}, f"np.random scene sampler never switched scene in 6 steps: {scenes}"
+    n = eng.n_obj
+    for k in (0, 1):
+        assert not torch.equal(p0[k * n:(k + 1) * n], eng.params[k * n:(k + 1) * n])
+    assert torch.isfinite(eng.params).all()
+    out = cfg.log.exp_dir
+    for name in ("mapper-steps-3_object.pt", "mapper-steps-3_view.pt", "mapper-final_object.pt", "mapper-final_view.pt",
+                 "learned_embeds-final.bin"):
+        assert (out / name).exists(), name
+    ids = coach.placeholder_object_token_ids
+    _, lookup = CheckpointHandler.load_mapper(out / "mapper-final_object.pt", "object", ["<skull>", "<statue>"], ids)
+    for k, tid in enumerate(ids):
+        flat = flatten_mapper_state(lookup[tid].mapper_state())
+        assert torch.equal(flat, eng.object_params(k).cpu()) and lookup[tid].hidden == 128
+    _, view = CheckpointHandler.load_mapper(out / "mapper-final_view.pt", "view")
+    assert torch.equal(flatten_mapper_state(view.mapper_state()), eng.view_params_flat().cpu())
+    assert view.bypass_unconstrained and view.use_nested_dropout

@@ -86,7 +86,8 @@ class CheckpointHandler:
                            pe_sigmas=mc.pe_sigmas, output_bypass=mc.output_bypass_view if is_view else mc.output_bypass_object,
                            bypass_unconstrained=unconstrained, output_bypass_alpha=alpha,
                            placeholder_object_token=entry["placeholder_object_token"], cam_mins=cam_mins,
-                           cam_maxs=cam_maxs)
+                           cam_maxs=cam_maxs, use_nested_dropout=mc.use_nested_dropout,
+                           nested_dropout_prob=mc.nested_dropout_prob)
             state = dict(entry["state_dict"])
             missing = set(m.mapper_state()) ^ set(state)
             if missing:

@@ -7,6 +7,9 @@ What is mirrored (file:line of the reference):
     super-category rows, mapper norm_scale = |E[super]|                 coach.py:320-397
   * one object mapper per placeholder token (+ view mapper in modes 1-3), all initialised right after the
     encoder's torch.manual_seed(0) (App. C Q1)                           coach.py:492-598
+  * learnable_mode 3: one object mapper per scene in one parameter bucket, the batch's scene picks the
+    mapper (device-side slot), a new scene is drawn after every optimizer step   coach.py:155-156, dataset.py:584-596
+  * nested dropout / unconstrained bypass flags forwarded to the mappers   coach.py:525-584
   * lr = lr * accum * batch * world when scale_lr                         coach.py:727-733
   * train loop, save every log.save_steps + final, file names            coach.py:137-274
 What differs on purpose: DESIGN.md §5 (no embedding restore, device RNG, flat-bucket all-reduce);
@@ -66,7 +69,11 @@ class Coach:
                      "SD-shaped synthetic weights")
         clip_w = self._extend_token_embedding(clip_w)
         self.mapper_object_lookup, self.mapper_view = self._init_neti_mappers()
-        first = next(iter(self.mapper_object_lookup.values()))
+        # engine slot k <-> k-th placeholder object token (mapper_object_lookup, coach.py:505-552)
+        self.object_slot = {tid: k for k, tid in enumerate(self.placeholder_object_token_ids)}
+        objs = [self.mapper_object_lookup[tid] for tid in self.placeholder_object_token_ids]
+        first = objs[0]
+        m = cfg.model
         bs = cfg.optim.train_batch_size
         lr = parallel.scaled_lr(cfg.optim.learning_rate, cfg.optim.gradient_accumulation_steps, bs, self.world,
                                 cfg.optim.scale_lr)
@@ -77,11 +84,13 @@ class Coach:
                       norm_scale_view=self.mapper_view.norm_scale, alpha_view=cfg.model.output_bypass_alpha_view,
                       train_view=cfg.learnable_mode != 5)
         self.engine = TrainStepEngine(
-            self.sd, unet_w, vae_w, clip_w, bs, h, w, first.mapper_state(), first.encoder.w, first.norm_scale,
-            cfg.model.output_bypass_alpha_object, lr=lr, betas=(cfg.optim.adam_beta1, cfg.optim.adam_beta2),
+            self.sd, unet_w, vae_w, clip_w, bs, h, w, [o.mapper_state() for o in objs], first.encoder.w,
+            first.norm_scale, m.output_bypass_alpha_object, lr=lr, betas=(cfg.optim.adam_beta1, cfg.optim.adam_beta2),
             adam_eps=cfg.optim.adam_epsilon, weight_decay=cfg.optim.adam_weight_decay,
             seed=parallel.data_seed(cfg.seed, self.rank), world_size=self.world, device=device,
-            grad_accum=cfg.optim.gradient_accumulation_steps, **kw)
+            grad_accum=cfg.optim.gradient_accumulation_steps, hidden_object=first.hidden,
+            unconstrained_object=m.bypass_unconstrained_object, unconstrained_view=m.bypass_unconstrained_view,
+            nested_dropout_prob=m.nested_dropout_prob if m.use_nested_dropout else 0.0, **kw)
         del unet_w, vae_w, clip_w
         self.checkpoint_handler = CheckpointHandler(
             cfg, self.train_dataset.placeholder_view_tokens, self.placeholder_view_token_ids,
@@ -163,28 +172,35 @@ class Coach:
         if m.arch_view_net != 15 or m.arch_view_disable_tl:
             raise NotImplementedError("the HIP engine implements the paper's arch_view_net=15 mappers "
                                       "(set --model.arch_view_net 15 --model.arch_view_disable_tl False)")
-        if m.use_nested_dropout or m.bypass_unconstrained_object or m.bypass_unconstrained_view or m.original_ti:
-            raise NotImplementedError("nested dropout / unconstrained bypass / original_ti are not wired in this round")
+        if m.original_ti:
+            raise NotImplementedError("original_ti (plain textual inversion baseline) is outside the NeTI hot path")
+        if not (m.output_bypass_object and (m.output_bypass_view or cfg.learnable_mode == 0)):
+            raise NotImplementedError("the HIP text path implements the paper's textual-bypass mappers "
+                                      "(model.output_bypass_object / output_bypass_view = True)")
         if len(UNET_LAYERS) != self.sd.unet.n_cross_layers:
             raise ValueError("UNET_LAYERS does not match the UNet")
         lookup = {}
         for token, token_id in zip(self.train_dataset.placeholder_object_tokens, self.placeholder_object_token_ids):
             lookup[token_id] = NeTIMapper("object", m.word_embedding_dim, m.arch_mlp_hidden_dims, m.target_norm_object,
-                                          m.pe_sigmas, m.output_bypass_object, False, m.output_bypass_alpha_object, token)
+                                          m.pe_sigmas, m.output_bypass_object, m.bypass_unconstrained_object,
+                                          m.output_bypass_alpha_object, token,
+                                          use_nested_dropout=m.use_nested_dropout,
+                                          nested_dropout_prob=m.nested_dropout_prob)
         view = None
         if cfg.learnable_mode in (1, 2, 3):
             ds = self.train_dataset
             cams = torch.stack(list(ds.lookup_camidx_to_cam_params.values()))
             view = NeTIMapper("view", m.word_embedding_dim, 64, m.target_norm_view, m.pe_sigmas, m.output_bypass_view,
-                              False, m.output_bypass_alpha_view, None, cams.min(0).values.flatten(),
-                              cams.max(0).values.flatten())
+                              m.bypass_unconstrained_view, m.output_bypass_alpha_view, None,
+                              cams.min(0).values.flatten(), cams.max(0).values.flatten(),
+                              use_nested_dropout=m.use_nested_dropout, nested_dropout_prob=m.nested_dropout_prob)
         elif cfg.learnable_mode in (4, 5):
             ds = self.train_dataset
             cams = torch.stack(list(ds.lookup_camidx_to_cam_params.values()))
             _, view = CheckpointHandler.load_mapper(m.pretrained_view_mapper, "view", cam_mins=cams.min(0).values.flatten(),
                                                     cam_maxs=cams.max(0).values.flatten())
-        if cfg.learnable_mode == 3 or len(lookup) != 1:
-            raise NotImplementedError("multi-object training (learnable_mode 3) needs per-scene mapper switching: next round")
+        if cfg.learnable_mode != 3 and len(lookup) != 1:
+            raise ValueError("only learnable_mode 3 trains more than one object token (dataset.py:612)")
         return lookup, view
 
     # ------------------------------------------------------------------ training
@@ -201,10 +217,11 @@ class Coach:
     def _sync_modules(self):
         """copy the trained flat bucket back into the nn.Module views used for checkpoints."""
         eng, D = self.engine, self.cfg.model.word_embedding_dim
-        obj = next(iter(self.mapper_object_lookup.values()))
-        obj.load_state_dict(unflatten_mapper_state(eng.params[: eng.n_obj].cpu(), 64, obj.hidden, 2 * D), strict=False)
-        if self.mapper_view is not None and eng.params.numel() > eng.n_obj:
-            self.mapper_view.load_state_dict(unflatten_mapper_state(eng.params[eng.n_obj:].cpu(), 64, 64, 2 * D),
+        for tid, k in self.object_slot.items():
+            obj = self.mapper_object_lookup[tid]
+            obj.load_state_dict(unflatten_mapper_state(eng.object_params(k).cpu(), 64, obj.hidden, 2 * D), strict=False)
+        if self.mapper_view is not None and eng.view_params_flat().numel() > 0:
+            self.mapper_view.load_state_dict(unflatten_mapper_state(eng.view_params_flat().cpu(), 64, 64, 2 * D),
                                              strict=False)
 
     def save(self, embeds_name: str, mapper_name: str):
@@ -224,14 +241,27 @@ class Coach:
                      f"  Total optimization steps = {cfg.optim.max_train_steps}"):
             self.log(line)
         global_step, captured, t0 = 0, False, time.time()
+        if cfg.learnable_mode == 3:
+            # every rank must draw the same scene each step (one all-reduce of that scene's mapper); the
+            # reference leaves np.random unseeded per process, which only works because its DDP wrapper never
+            # sees the dict-held object mappers
+            import numpy as np
+            np.random.seed(cfg.seed if cfg.seed is not None else 0)
         while global_step < cfg.optim.max_train_steps:
             for batch in self.train_dataloader:
-                eng.set_batch(batch["pixel_values"], batch["input_ids"], batch["input_ids_placeholder_object"],
-                              batch["input_ids_placeholder_view"], self._view_params(batch["input_ids_placeholder_view"]))
+                ids_obj = batch["input_ids_placeholder_object"]
+                if not bool((ids_obj == ids_obj[0]).all()):
+                    raise ValueError("a batch must hold a single object token (net_clip_text_embedding.py:67-68)")
+                eng.set_batch(batch["pixel_values"], batch["input_ids"], ids_obj, batch["input_ids_placeholder_view"],
+                              self._view_params(batch["input_ids_placeholder_view"]),
+                              object_index=self.object_slot[int(ids_obj[0])])
                 if not captured:
                     eng.capture()
                     captured = True
-                if eng.step():
+                stepped = eng.step()
+                if stepped and cfg.learnable_mode == 3:
+                    self.train_dataset.reset_sampled_object()  # new scene only once the accumulation group is done
+                if stepped:
                     global_step += 1
                     if global_step % 50 == 0 or global_step == 1:
                         self.log(f"step {global_step} loss {eng.loss():.5f} lr {float(eng.hyper[0]):.2e} "
