@@ -107,6 +107,38 @@ def roofline_pass(eng, reps=3):
     return out
 
 
+def usable_cores(cap: int = 32) -> int:
+    """threads the CPU leg really gets: scheduler affinity and the cgroup CPU quota, capped (a 256-thread
+    pool on the GPU box's host ran the oracle at <1 GFLOP/s — oversubscription, not a baseline)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline_bounded(args, timeout_s: int = 240):
+    """run cpu_baseline() in a child process under a hard wall-clock bound so the default bench run
+    always finishes within minutes; a timeout is reported, never hidden."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", args.model, "--batch",
+           str(args.batch), "--resolution", str(args.resolution), "--cpu-resolution", str(args.cpu_resolution)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "steps/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"cpu baseline child failed (rc={r.returncode}): {r.stderr.strip()[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "steps/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"oracle/sd_ref.py step at bs=1 {args.cpu_resolution}x{args.cpu_resolution} did not finish "
+                          f"within the {timeout_s}s bound"}
+
+
 def cpu_baseline(args):
     """The oracle's train step on the host cores, on a bounded sample of the same workload
     (same SD-1.5 weights; bs=1 at a reduced resolution so the default run stays within minutes);
@@ -114,7 +146,7 @@ def cpu_baseline(args):
     from oracle import sd_ref as R
     from view_neti_amd import sd_config as sc, synth
     from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = sc.CONFIGS[args.model]()
     dev = "cuda" if torch.cuda.is_available() else "cpu"
@@ -159,10 +191,14 @@ def main():
     ap.add_argument("--model", default="sd15")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--resolution", type=int, default=512)
-    ap.add_argument("--cpu-resolution", type=int, default=256)
+    ap.add_argument("--cpu-resolution", type=int, default=128)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -228,7 +264,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del eng
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline_bounded(args)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

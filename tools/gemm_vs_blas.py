@@ -6,6 +6,7 @@ import torch
 from view_neti_amd import ops
 
 dev = "cuda"
+HINTS = tuple(int(h) for h in os.environ.get("HINTS", "1,2,4,5").split(","))
 ops.set_default_gemm_workspace(torch.empty(16 * 2 ** 20, dtype=torch.float32, device=dev))
 SHAPES = [
     (4096, 4096, 4096),
@@ -37,7 +38,7 @@ for M, N, K in SHAPES:
     C = torch.empty(M, N, device=dev, dtype=torch.float16)
     Bt = B.t()
     t_blas = timeit(lambda: torch.matmul(A, Bt, out=C))
-    ts = {h: timeit(lambda: ops.gemm(A, B, C, tile_hint=h)) for h in (1, 2, 4, 5)}
+    ts = {h: timeit(lambda: ops.gemm(A, B, C, tile_hint=h)) for h in HINTS}
     best = min(ts, key=ts.get)
     gf = 2.0 * M * N * K / 1e9
     print(f"M={M:8d} N={N:6d} K={K:6d} {gf:9.1f}GF | blas {t_blas:9.1f}us {gf / t_blas * 1e3:6.0f}TF | ours h{best} "
