@@ -63,7 +63,8 @@ def build_engine(args, rank, world):
     sd = init_mapper_state(64, 64, D)
     lr = 1e-3 * args.batch * world  # scale_lr rule of training/coach.py:728-733 (accum = 1)
     eng = TrainStepEngine(cfg, uw, vw, cw, args.batch, args.resolution, args.resolution, sd, w_enc, norm_scale, 0.2,
-                          lr=lr, seed=1234 + rank, world_size=world, device_rng=True)
+                          lr=lr, seed=1234 + rank, world_size=world, device_rng=True,
+                          overlap=os.environ.get("VNETI_NO_OVERLAP", "0") != "1")
     del uw, vw, cw
     ids = synth.input_ids(args.batch, placeholder_id, cfg.clip.vocab_size)
     eng.set_batch(synth.pixel_values(args.batch, args.resolution, args.resolution, seed=1 + rank), ids,
@@ -105,6 +106,30 @@ def roofline_pass(eng, reps=3):
         out[tile] = dict(n=n, total_ms=total_ms, avg_us=total_ms * 1e3 / n, flops_per_launch=g["flops"] / n,
                          tflops=g["flops"] / (total_ms * 1e-3) / 1e12)
     return out
+
+
+def pmc_traffic(tile_name: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes
+    (profiles/*_pmc.json, written by tools/profile_round.sh + tools/pmc_summary.py: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    bench.py cannot run the counter passes itself, so `traffic` is null until a profile is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.json")))
+    if not files:
+        return {"traffic": None}
+    dims = re.findall(r"\d+", tile_name)
+    pats = ["gemm_kernel<" + ", ".join(dims) + ", false", "gemm_kernelILi" + "ELi".join(dims) + "ELb0E"]
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return {"traffic": None}
+    for name, e in ks.items():
+        if any(p in name for p in pats):
+            return {"traffic": e["hbm_bytes"], "traffic_source": os.path.basename(files[-1]),
+                    "traffic_note": "mean HBM bytes/launch over this kernel's launches in one eager train step "
+                                    "(FETCH_SIZE x2 + WRITE_SIZE)"}
+    return {"traffic": None}
 
 
 def usable_cores(cap: int = 32) -> int:
@@ -191,10 +216,11 @@ def main():
     ap.add_argument("--model", default="sd15")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--resolution", type=int, default=512)
-    ap.add_argument("--cpu-resolution", type=int, default=128)
+    ap.add_argument("--cpu-resolution", type=int, default=512)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-tile GEMM replay (counter-collection runs)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
@@ -236,7 +262,9 @@ def main():
         dt = float(tmax.item())
     loss = eng.loss()
 
-    if rank == 0:
+    if rank == 0 and args.no_roofline:
+        print(json.dumps({"value": world * args.steps / dt, "unit": "steps/s", "note": "roofline pass skipped"}))
+    elif rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.steps / dt
         rf = roofline_pass(eng)
@@ -255,7 +283,8 @@ def main():
                                                / (ms * 1e-3) / MFMA_PEAK_TFLOPS,
                        "engine_gib": eng.memory_bytes() / 2 ** 30},
             "roofline": {"kernel": TILE_NAMES[dom], "bound": "mfma", "achieved": d["tflops"], "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": d["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": d["tflops"] / MFMA_PEAK_TFLOPS,
+                         **pmc_traffic(TILE_NAMES[dom]),
                          "launches_per_step": d["n"], "avg_launch_us": d["avg_us"],
                          "algorithmic_gflop_per_launch": d["flops_per_launch"] / 1e9,
                          "all_gemm_tiles": {TILE_NAMES[k]: {"launches": v["n"], "ms_per_step": v["total_ms"],

@@ -94,6 +94,17 @@ int vneti_im2col3x3_small(const void* x, int x_is_f32, long long sb, long long s
 int vneti_transpose_f16(const void* in, long long ld_in, long long stride_in, void* out,
                         long long ld_out, long long stride_out, int rows, int cols, int batch,
                         void* stream);
+/* up to VNETI_TRANSPOSE_MAX independent transposes in ONE launch (the Q^T / K^T / dO^T operand copies of
+ * an attention backward): fields as the arguments of vneti_transpose_f16. */
+#define VNETI_TRANSPOSE_MAX 4
+typedef struct vneti_transpose_desc {
+  const void* in;
+  long long ld_in, stride_in;
+  void* out;
+  long long ld_out, stride_out;
+  int rows, cols, batch, _pad;
+} vneti_transpose_desc;
+int vneti_transpose_f16_multi(const vneti_transpose_desc* descs, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) on NHWC f16, statistics in f32.
@@ -144,10 +155,13 @@ int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long long ldk, c
 /* delta[b][h][q] = sum_d dO*O  (f32) */
 int vneti_attn_bwd_delta(const void* dO, long long lddo, const void* O, long long ldo,
                          float* delta, int Bn, int H, int Nq, int D, void* stream);
+/* dQ.  With O == NULL, delta is an input (from vneti_attn_bwd_delta).  With O given, the kernel computes
+ * delta itself from the dO rows it already holds and WRITES it to `delta` for the dK/dV kernel that
+ * follows — one launch fewer per attention. */
 int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, long long ldk, const void* Kt,
                       long long ldkt, const void* V, long long ldv, const void* dO,
-                      long long lddo, const float* lse, const float* delta, void* dQ,
-                      long long lddq, int Bn, int H, int Nq, int Nk, int D, float scale,
+                      long long lddo, const float* lse, float* delta, const void* O, long long ldo,
+                      void* dQ, long long lddq, int Bn, int H, int Nq, int Nk, int D, float scale,
                       int causal, void* stream);
 int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, long long ldqt,
                        const void* K, long long ldk, const void* V, long long ldv,

@@ -315,9 +315,13 @@ def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
     qt = torch.zeros(Bn, Cc, ldq, dtype=torch.float16, device=DEV)
     dot = torch.zeros(Bn, Cc, ldq, dtype=torch.float16, device=DEV)
     ops.transpose(vd, vt, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk)
-    ops.transpose(kd, kt, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk)
-    ops.transpose(qd, qt, Nq, Cc, Bn, Cc, Nq * Cc, ldq, Cc * ldq)
-    ops.transpose(dod, dot, Nq, Cc, Bn, Cc, Nq * Cc, ldq, Cc * ldq)
+    # the three backward operand copies in one launch (different shapes/batch strides per descriptor)
+    ops.transpose_multi([(kd, kt, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk), (qd, qt, Nq, Cc, Bn, Cc, Nq * Cc, ldq, Cc * ldq),
+                         (dod, dot, Nq, Cc, Bn, Cc, Nq * Cc, ldq, Cc * ldq)])
+    kt1 = torch.zeros_like(kt)
+    ops.transpose(kd, kt1, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk)
+    assert torch.equal(kt, kt1) and torch.equal(qt[:, :, :Nq], q.to(DEV).transpose(1, 2))
+    assert torch.equal(dot[:, :, :Nq], do.to(DEV).transpose(1, 2))
     o = torch.zeros(Bn * Nq, Cc, dtype=torch.float16, device=DEV)
     lse = torch.zeros(Bn, H, Nq, dtype=torch.float32, device=DEV)
     ops.attn_fwd(qd, kd, vt, o, lse, Bn, H, Nq, Nk, D, scale, causal, ldk)
@@ -332,7 +336,14 @@ def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
     dk = torch.zeros(Bn * Nk, Cc, dtype=torch.float16, device=DEV)
     dv = torch.zeros(Bn * Nk, Cc, dtype=torch.float16, device=DEV)
     ops.attn_bwd_dq(qd, kd, kt, ldk, vd, dod, lse, delta, dq, Bn, H, Nq, Nk, D, scale, causal)
-    ops.attn_bwd_dkv(qd, qt, ldq, kd, vd, dod, dot, ldq, lse, delta, dk, dv, Bn, H, Nq, Nk, D, scale, causal)
+    # fused variant: delta computed inside the dQ kernel and published for dK/dV
+    delta2 = torch.full_like(delta, float("nan"))
+    dq2 = torch.zeros_like(dq)
+    ops.attn_bwd_dq(qd, kd, kt, ldk, vd, dod, lse, delta2, dq2, Bn, H, Nq, Nk, D, scale, causal, O=o)
+    torch.cuda.synchronize()
+    check(f"attn delta(in-kernel) {tag}", delta2, delta, 1e-4)
+    check(f"attn dq(fused delta) {tag}", dq2, dq, 1e-3)
+    ops.attn_bwd_dkv(qd, qt, ldq, kd, vd, dod, dot, ldq, lse, delta2, dk, dv, Bn, H, Nq, Nk, D, scale, causal)
     torch.cuda.synchronize()
     check(f"attn dq {tag}", dq.view(Bn, Nq, Cc), qr.grad, 6e-3)
     check(f"attn dk {tag}", dk.view(Bn, Nk, Cc), kr.grad, 6e-3)

@@ -38,6 +38,8 @@ struct AttnArgs {
   float* lse;
   const float* lse_in;
   const float* delta;
+  float* delta_out;      // dQ kernel with O given: delta is computed in-kernel and published here
+  const half_t* O_in;    //   (saves the separate delta launch; the dK/dV kernel then runs after dQ)
   long long ldq, ldk, ldv, ldkt, ldvt, ldqt, ldo, lddo, lddot, lddq, lddk, lddv;
   int Bn, H, Nq, Nk, D;
   float scale;
@@ -380,9 +382,26 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
   }
   const float c = a.scale * LOG2E;
   float lse2 = INFINITY, dlt = 0.f;
+  if (a.O_in) {
+    // delta[q] = sum_d dO[q][d] * O[q][d]: the lane already holds its half of the dO row as MFMA fragments
+    __amdgpu_buffer_rsrc_t rsO = vn_make_rsrc(a.O_in, (uint32_t)((long long)a.Bn * a.Nq * a.ldo * 2));
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      int ch = ks * 2 + h2;
+      uint32_t offo = (qok && ch < C::DCH)
+                          ? (uint32_t)((((long long)b * a.Nq + q) * a.ldo + h * D + ch * 8) * 2)
+                          : VN_OOB;
+      half8 of = as_half8(vn_buf_load16(rsO, offo));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += (float)dof[ks][j] * (float)of[j];
+    }
+    dlt = part + __shfl_xor(part, 32, 64);
+    if (qok && h2 == 0) a.delta_out[((long long)b * a.H + h) * a.Nq + q] = dlt;
+  }
   if (qok) {
     lse2 = a.lse_in[((long long)b * a.H + h) * a.Nq + q] * LOG2E;
-    dlt = a.delta[((long long)b * a.H + h) * a.Nq + q];
+    if (!a.O_in) dlt = a.delta[((long long)b * a.H + h) * a.Nq + q];
   }
 
   constexpr int KIT = (64 * C::DCH + 255) / 256;
@@ -826,11 +845,13 @@ extern "C" int vneti_attn_bwd_delta(const void* dO, long long lddo, const void* 
 
 extern "C" int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, long long ldk, const void* Kt,
                                  long long ldkt, const void* V, long long ldv, const void* dO, long long lddo,
-                                 const float* lse, const float* delta, void* dQ, long long lddq, int Bn, int H,
-                                 int Nq, int Nk, int D, float scale, int causal, void* stream) {
+                                 const float* lse, float* delta, const void* O, long long ldo, void* dQ,
+                                 long long lddq, int Bn, int H, int Nq, int Nk, int D, float scale, int causal,
+                                 void* stream) {
   int rc = check_common(Bn, H, Nq, Nk, D);
   VN_REQUIRE(rc == 0, "attn_bwd_dq: unsupported shape B=%d H=%d Nq=%d Nk=%d D=%d", Bn, H, Nq, Nk, D);
   VN_REQUIRE(Q && K && Kt && V && dO && lse && delta && dQ, "attn_bwd_dq: null pointer");
+  VN_REQUIRE(!O || ldo % 8 == 0, "attn_bwd_dq: ldo must be a multiple of 8");
   VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldkt % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 &&
                  ldkt >= Nk,
              "attn_bwd_dq: bad strides");
@@ -844,6 +865,9 @@ extern "C" int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, lo
   a.dQ = (half_t*)dQ;
   a.lse_in = lse;
   a.delta = delta;
+  a.delta_out = delta;
+  a.O_in = (const half_t*)O;
+  a.ldo = ldo;
   a.ldq = ldq;
   a.ldk = ldk;
   a.ldkt = ldkt;

@@ -37,6 +37,49 @@ __global__ __launch_bounds__(256) void transpose_kernel(const half_t* __restrict
   }
 }
 
+struct TMulti {
+  vneti_transpose_desc d[VNETI_TRANSPOSE_MAX];
+  int n;
+};
+
+// several independent transposes in one grid: blockIdx.z walks the concatenated batches
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TMulti m) {
+  __shared__ half_t tile[64][66];
+  int z = blockIdx.z, k = 0;
+  while (k < m.n - 1 && z >= m.d[k].batch) {
+    z -= m.d[k].batch;
+    ++k;
+  }
+  const vneti_transpose_desc& d = m.d[k];
+  const int rows = d.rows, cols = d.cols;
+  const long long ld_in = d.ld_in, ld_out = d.ld_out;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  if (r0 >= ld_out || c0 >= cols) return;  // grid is sized for the largest descriptor
+  const half_t* ib = (const half_t*)d.in + (long long)z * d.stride_in;
+  half_t* ob = (half_t*)d.out + (long long)z * d.stride_out;
+  for (int idx = threadIdx.x; idx < 512; idx += 256) {
+    int r = idx >> 3, ch = idx & 7;
+    int gr = r0 + r, gc = c0 + ch * 8;
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+    if (gr < rows && gc < cols) v = *reinterpret_cast<const half8*>(ib + (long long)gr * ld_in + gc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[r][ch * 8 + j] = v[j];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 512; idx += 256) {
+    int c = idx & 63, rch = idx >> 6;
+    int gc = c0 + c, gr = r0 + rch * 8;
+    if (gc < cols && gr < ld_out) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[rch * 8 + j][c];
+      *reinterpret_cast<half8*>(ob + (long long)gc * ld_out + gr) = v;
+    }
+  }
+}
+
 // out[m][k], k = tap*C + c for tap<9, c<C; zero for k >= 9*C (row length 64).
 template <bool XF32>
 __global__ __launch_bounds__(256) void im2col_small_kernel(const void* __restrict__ x, long long sb, long long sc,
@@ -82,6 +125,25 @@ extern "C" int vneti_transpose_f16(const void* in, long long ld_in, long long st
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)in, ld_in,
                      stride_in, (half_t*)out, ld_out, stride_out, rows, cols);
   return vneti_check_launch("transpose");
+}
+
+extern "C" int vneti_transpose_f16_multi(const vneti_transpose_desc* descs, int n, void* stream) {
+  VN_REQUIRE(descs && n >= 1 && n <= VNETI_TRANSPOSE_MAX, "transpose_multi: need 1..%d descriptors", VNETI_TRANSPOSE_MAX);
+  TMulti m;
+  m.n = n;
+  int gx = 0, gy = 0, gz = 0;
+  for (int i = 0; i < n; ++i) {
+    const vneti_transpose_desc& d = descs[i];
+    VN_REQUIRE(d.in && d.out && d.rows > 0 && d.cols > 0 && d.batch > 0, "transpose_multi[%d]: bad arguments", i);
+    VN_REQUIRE(d.cols % 8 == 0 && d.ld_in % 8 == 0 && d.ld_out % 8 == 0 && d.ld_out >= d.rows,
+               "transpose_multi[%d]: cols/ld must be multiples of 8 and ld_out >= rows", i);
+    m.d[i] = d;
+    gx = gx > cdiv((int)d.ld_out, 64) ? gx : cdiv((int)d.ld_out, 64);
+    gy = gy > cdiv(d.cols, 64) ? gy : cdiv(d.cols, 64);
+    gz += d.batch;
+  }
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3(gx, gy, gz), dim3(256), 0, (hipStream_t)stream, m);
+  return vneti_check_launch("transpose_multi");
 }
 
 extern "C" int vneti_im2col3x3_small(const void* x, int x_is_f32, long long sb, long long sc, long long sy,

@@ -129,8 +129,9 @@ class Schedule:
 
     def autotune(self, candidates=(1, 2, 3, 4, 5), reps=4):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
-        tile configuration (split-K stays on its heuristic) and pin the fastest.  ~0.3 s per
-        engine; results are cached per problem signature across engines."""
+        tile configuration, with the split-K heuristic and with split-K forced off (the f32 partials
+        and the reduce launch are not always worth the extra blocks), and pin the fastest pair.
+        ~0.5 s per engine; results are cached per problem signature across engines."""
         if not torch.cuda.is_available():
             return
         cache = Schedule._tile_cache
@@ -140,23 +141,24 @@ class Schedule:
                     continue
                 key = self._gemm_key(f)
                 if key not in cache:
-                    best, best_t = 0, float("inf")
+                    best, best_t = (0, 0), float("inf")
                     for h in candidates:
-                        kw = dict(f.keywords)
-                        kw["tile_hint"] = h
-                        ops.gemm(*f.args, **kw)
-                        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        s.record()
-                        for _ in range(reps):
+                        for sk in (0, 1):  # 0 = library heuristic, 1 = no split
+                            kw = dict(f.keywords)
+                            kw["tile_hint"], kw["split_k"] = h, sk
                             ops.gemm(*f.args, **kw)
-                        e.record()
-                        e.synchronize()
-                        t = s.elapsed_time(e)
-                        if t < best_t:
-                            best, best_t = h, t
+                            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            s.record()
+                            for _ in range(reps):
+                                ops.gemm(*f.args, **kw)
+                            e.record()
+                            e.synchronize()
+                            t = s.elapsed_time(e)
+                            if t < best_t:
+                                best, best_t = (h, sk), t
                     cache[key] = best
                 kw = dict(f.keywords)
-                kw["tile_hint"] = cache[key]
+                kw["tile_hint"], kw["split_k"] = cache[key]
                 lst[idx] = partial(ops.gemm, *f.args, **kw)
 
     def bind_workspace(self):

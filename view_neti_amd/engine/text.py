@@ -273,19 +273,20 @@ class TextEngine(Schedule):
             do = self._tmp("cD", Rt, D)
             bw.append(partial(ops.gemm, g16, r["wod"], do))
             delta = self._tmp("cdelta", R * H, L, torch.float32)
-            bw.append(partial(ops.attn_bwd_delta, do, r["o"], delta, R, H, L, hd))
             qt = self._tmp("cQt", R * D, ldn)
             kt = self._tmp("cKt", R * D, ldn)
             dot = self._tmp("cdOt", R * D, ldn)
-            bw.append(partial(ops.transpose, q, qt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn))
-            bw.append(partial(ops.transpose, k, kt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn))
-            bw.append(partial(ops.transpose, do, dot, L, D, R, D, L * D, ldn, D * ldn))
+            bw.append(partial(ops.transpose_multi, [(q, qt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn),
+                                                    (k, kt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn),
+                                                    (do, dot, L, D, R, D, L * D, ldn, D * ldn)]))
             dqkv = self._tmp("cE", Rt, 3 * D)
             dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
             sc_ = hd ** -0.5
+            # dQ first: it also produces delta = rowsum(dO o O) for the dK/dV kernel
+            bw.append(partial(ops.attn_bwd_dq, q, k, kt, ldn, v, do, r["lse"], delta, dq, R, H, L, L, hd, sc_, True,
+                              O=r["o"]))
             bw.append(partial(ops.attn_bwd_dkv, q, qt, ldn, k, v, do, dot, ldn, r["lse"], delta, dk, dv, R, H, L, L,
                               hd, sc_, True))
-            bw.append(partial(ops.attn_bwd_dq, q, k, kt, ldn, v, do, r["lse"], delta, dq, R, H, L, L, hd, sc_, True))
             dn1 = self._tmp("cC", Rt, D)
             bw.append(partial(ops.gemm, dqkv, r["wqkvd"], dn1))
             bw.append(partial(self._ln_bwd, r["ln1"], dn1, dx, dxm))          # dx_in = LN1'(dn1) + dx_mid

@@ -189,12 +189,22 @@ class UNetEngine(Schedule):
         do2 = self._tmp("tA", M, Cc)  # dh3 is dead
         bw.append(partial(ops.gemm, dh2, r["wo2d"], do2))
         delta = self._tmp("tdelta", B * heads, N, torch.float32)
-        bw.append(partial(ops.attn_bwd_delta, do2, r["o2"], delta, B, heads, N, D))
         ldn, ldl = r["ldn"], r["ldl"]
         q2t = self._tmp("tQt", B * Cc, ldn)
         do2t = self._tmp("tdOt", B * Cc, ldn)
-        bw.append(partial(ops.transpose, r["q2"], q2t, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn))
-        bw.append(partial(ops.transpose, do2, do2t, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn))
+        k2t = self._tmp("tK2t", B * Cc, ldl)
+        dq2 = self._tmp("tD", M, Cc)  # dn3 is dead
+        # the transposed operand copies of this attention in ONE launch; delta = rowsum(dO o O) comes out of
+        # the dQ kernel, which therefore runs before dK/dV
+        tr = [(r["q2"], q2t, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn), (do2, do2t, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn)]
+        if r["need_dx"]:
+            tr.append((r["k2"], k2t, L, Cc, B, Cc, L * Cc, ldl, Cc * ldl))
+        bw.append(partial(ops.transpose_multi, tr))
+        if r["need_dx"]:
+            bw.append(partial(ops.attn_bwd_dq, r["q2"], r["k2"], k2t, ldl, r["v2"], do2, r["lse2"], delta, dq2, B,
+                              heads, N, L, D, r["scale"], False, O=r["o2"]))
+        else:
+            bw.append(partial(ops.attn_bwd_delta, do2, r["o2"], delta, B, heads, N, D))
         dk2 = self._tmp("tdk2", B * L, Cc)
         dv2 = self._tmp("tdv2", B * L, Cc)
         bw.append(partial(ops.attn_bwd_dkv, r["q2"], q2t, ldn, r["k2"], r["v2"], do2, do2t, ldn, r["lse2"], delta,
@@ -203,11 +213,6 @@ class UNetEngine(Schedule):
         bw.append(partial(ops.gemm, dv2, r["wv2d"], self.dctx_v[li]))
         if not r["need_dx"]:
             return
-        k2t = self._tmp("tK2t", B * Cc, ldl)
-        bw.append(partial(ops.transpose, r["k2"], k2t, L, Cc, B, Cc, L * Cc, ldl, Cc * ldl))
-        dq2 = self._tmp("tD", M, Cc)  # dn3 is dead
-        bw.append(partial(ops.attn_bwd_dq, r["q2"], r["k2"], k2t, ldl, r["v2"], do2, r["lse2"], delta, dq2, B, heads,
-                          N, L, D, r["scale"], False))
         dn2 = self._tmp("tA", M, Cc)  # do2 is dead after dq
         bw.append(partial(ops.gemm, dq2, r["wq2d"], dn2))
         dh1 = self._tmp("tF", M, Cc)
@@ -215,21 +220,20 @@ class UNetEngine(Schedule):
         # ---- attn1 backward ----
         do1 = self._tmp("tA", M, Cc)
         bw.append(partial(ops.gemm, dh1, r["wo1d"], do1))
-        bw.append(partial(ops.attn_bwd_delta, do1, r["o1"], delta, B, heads, N, D))
         qkv = r["qkv"]
         q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
         qt = self._tmp("tQt", B * Cc, ldn)
         dot = self._tmp("tdOt", B * Cc, ldn)
         kt = self._tmp("tKt", B * Cc, ldn)
-        bw.append(partial(ops.transpose, q, qt, N, Cc, B, 3 * Cc, N * 3 * Cc, ldn, Cc * ldn))
-        bw.append(partial(ops.transpose, do1, dot, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn))
-        bw.append(partial(ops.transpose, k, kt, N, Cc, B, 3 * Cc, N * 3 * Cc, ldn, Cc * ldn))
+        bw.append(partial(ops.transpose_multi, [(q, qt, N, Cc, B, 3 * Cc, N * 3 * Cc, ldn, Cc * ldn),
+                                                (do1, dot, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn),
+                                                (k, kt, N, Cc, B, 3 * Cc, N * 3 * Cc, ldn, Cc * ldn)]))
         dqkv = self._tmp("tC", M, 3 * Cc)  # dp is dead
         dq, dk, dv = dqkv[:, :Cc], dqkv[:, Cc:2 * Cc], dqkv[:, 2 * Cc:]
+        bw.append(partial(ops.attn_bwd_dq, q, k, kt, ldn, v, do1, r["lse1"], delta, dq, B, heads, N, N, D,
+                          r["scale"], False, O=r["o1"]))
         bw.append(partial(ops.attn_bwd_dkv, q, qt, ldn, k, v, do1, dot, ldn, r["lse1"], delta, dk, dv, B, heads, N, N,
                           D, r["scale"], False))
-        bw.append(partial(ops.attn_bwd_dq, q, k, kt, ldn, v, do1, r["lse1"], delta, dq, B, heads, N, N, D,
-                          r["scale"], False))
         dn1 = self._tmp("tD", M, Cc)
         bw.append(partial(ops.gemm, dqkv, r["wqkvd"], dn1))
         dh0 = self._tmp("tE", M, Cc)  # dh2 is dead

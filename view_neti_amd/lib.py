@@ -22,6 +22,13 @@ c_int = C.c_int
 c_f = C.c_float
 
 
+class TransposeDesc(C.Structure):
+    """Mirror of `vneti_transpose_desc` (include/vneti.h)."""
+
+    _fields_ = [("inp", c_vp), ("ld_in", c_ll), ("stride_in", c_ll), ("out", c_vp), ("ld_out", c_ll),
+                ("stride_out", c_ll), ("rows", c_int), ("cols", c_int), ("batch", c_int), ("_pad", c_int)]
+
+
 class GemmDesc(C.Structure):
     """Mirror of `vneti_gemm_desc` (include/vneti.h)."""
 
@@ -109,6 +116,7 @@ def call(name: str, *args):
 SIGNATURES = {
     "im2col3x3_small": [c_vp, c_int, c_ll, c_ll, c_ll, c_ll, c_vp] + [c_int] * 9 + [c_vp],
     "transpose_f16": [c_vp, c_ll, c_ll, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
+    "transpose_f16_multi": [c_vp, c_int, c_vp],
     "groupnorm_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                       c_f, c_int, c_vp],
     "groupnorm_bwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp,
@@ -119,7 +127,7 @@ SIGNATURES = {
     "attn_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_int,
                  c_f, c_int, c_vp],
     "attn_bwd_delta": [c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_vp],
-    "attn_bwd_dq": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_ll,
+    "attn_bwd_dq": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll,
                     c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
     "attn_bwd_dkv": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp,
                      c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp, c_ll, c_vp],

@@ -92,6 +92,17 @@ def transpose(inp, out, rows, cols, batch, ld_in, stride_in, ld_out, stride_out)
     _l.call("transpose_f16", _p(inp), ld_in, stride_in, _p(out), ld_out, stride_out, rows, cols, batch, stream())
 
 
+def transpose_multi(items):
+    """items: up to 4 tuples with the arguments of `transpose`; one launch for all of them."""
+    import ctypes
+    arr = (_l.TransposeDesc * len(items))()
+    for d, (inp, out, rows, cols, batch, ld_in, stride_in, ld_out, stride_out) in zip(arr, items):
+        d.inp, d.ld_in, d.stride_in = _p(inp), ld_in, stride_in
+        d.out, d.ld_out, d.stride_out = _p(out), ld_out, stride_out
+        d.rows, d.cols, d.batch = rows, cols, batch
+    _l.call("transpose_f16_multi", ctypes.addressof(arr), len(items), stream())
+
+
 def groupnorm_ws_floats(Bn, HW, Cc, G):
     n = _l.load().vneti_groupnorm_ws_floats(Bn, HW, Cc, G)
     if n < 0:
@@ -133,9 +144,11 @@ def attn_bwd_delta(dO, O, delta, Bn, H, Nq, D):
     _l.call("attn_bwd_delta", _p(dO), _ld(dO), _p(O), _ld(O), _p(delta), Bn, H, Nq, D, stream())
 
 
-def attn_bwd_dq(Q, K, Kt, ldkt, V, dO, lse, delta, dQ, Bn, H, Nq, Nk, D, scale, causal):
+def attn_bwd_dq(Q, K, Kt, ldkt, V, dO, lse, delta, dQ, Bn, H, Nq, Nk, D, scale, causal, O=None):
+    """O given: delta is computed inside the kernel and written to `delta` (no attn_bwd_delta launch)."""
     _l.call("attn_bwd_dq", _p(Q), _ld(Q), _p(K), _ld(K), _p(Kt), ldkt, _p(V), _ld(V), _p(dO), _ld(dO),
-            _p(lse), _p(delta), _p(dQ), _ld(dQ), Bn, H, Nq, Nk, D, scale, 1 if causal else 0, stream())
+            _p(lse), _p(delta), _p(O), _ld(O) if O is not None else 0, _p(dQ), _ld(dQ), Bn, H, Nq, Nk, D, scale,
+            1 if causal else 0, stream())
 
 
 def attn_bwd_dkv(Q, Qt, ldqt, K, V, dO, dOt, lddot, lse, delta, dK, dV, Bn, H, Nq, Nk, D, scale, causal,
