@@ -21,13 +21,13 @@ sc = D ** -0.5
 def run():
     ops.attn_fwd(q, k, vt, o, lse, B, H, N, Nk, D, sc, False, ld)
     ops.attn_bwd_delta(do, o, delta, B, H, N, D)
-    ops.attn_bwd_dq(q, k, kt, ld, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False)
+    ops.attn_bwd_dq(q, k, kt, ld, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False, O=o)
     ops.attn_bwd_dkv(q, qt, ldq, k, v, do, dot, ldq, lse, delta, dk, dv, B, H, N, Nk, D, sc, False)
 for _ in range(3): run()
 torch.cuda.synchronize()
 import time
 for name, fn in (("fwd", lambda: ops.attn_fwd(q, k, vt, o, lse, B, H, N, Nk, D, sc, False, ld)),
-                 ("dq", lambda: ops.attn_bwd_dq(q, k, kt, ld, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False)),
+                 ("dq", lambda: ops.attn_bwd_dq(q, k, kt, ld, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False, O=o)),
                  ("dkv", lambda: ops.attn_bwd_dkv(q, qt, ldq, k, v, do, dot, ldq, lse, delta, dk, dv, B, H, N, Nk, D, sc, False))):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

@@ -84,7 +84,7 @@ __device__ __forceinline__ half8 load_tfrag(const char* base, int row_bytes, int
 template <int D>
 // min 2 blocks/CU caps the register budget at 256, which makes the compiler keep MFMA accumulators in
 // arch VGPRs (no v_accvgpr copies around the softmax VALU work)
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnArgs a) {
   using C = Cfg<D>;
   // each wave owns QW independent 32-query sub-tiles: K/V fragments are read from LDS once and
   // used QW times, and the two softmax/MFMA dependency chains interleave inside the wave
