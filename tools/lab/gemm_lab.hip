@@ -34,7 +34,17 @@ extern "C" __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void lab_ker
   constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64, RSTEP = NT / 8;
   constexpr int A_IT = BM / RSTEP, B_IT = BN / RSTEP, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
+#ifdef XPF
+#ifndef XBK
+#define XBK 32
+#endif
+#ifndef XST
+#define XST 3
+#endif
+  __shared__ __attribute__((aligned(16))) char smem[XST * (BM + BN) * XBK * 2];
+#else
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
@@ -68,7 +78,82 @@ extern "C" __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void lab_ker
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int nk = K / 64;
   const int frow = lane & 31, fhalf = lane >> 5;
-#if STAGES == 2
+  (void)nk;
+#ifdef XPF
+  // ---- cross-barrier fragment prefetch: XST stages of BK=XBK, the fragments of step s+1 are read from LDS
+  // (stage made visible by the previous barrier) under the MFMAs of step s --------------------------------
+  {
+    constexpr int KSUB = XBK / 16;               // k16 sub-steps per stage
+    constexpr int ROWB = XBK * 2;                // bytes per LDS row
+    constexpr int CPR = ROWB / 16;               // 16-B chunks per row
+    constexpr int XSTAGE = (BM + BN) * ROWB;
+    constexpr int RPP = NT / CPR;                // rows per DMA pass of the whole block
+    constexpr int XA_IT = BM / RPP, XB_IT = BN / RPP;
+    constexpr int RPW = 64 / CPR;                // rows per wave-instruction
+    const int xrow = tid / CPR, xslot = tid % CPR;
+    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+    const int xchunk = xslot ^ swz(xrow);
+    int xa[XA_IT], xb[XB_IT];
+#pragma unroll
+    for (int i = 0; i < XA_IT; ++i) { int m = m0 + xrow + RPP * i; xa[i] = m < M ? m * K * 2 + xchunk * 16 : -1; }
+#pragma unroll
+    for (int i = 0; i < XB_IT; ++i) { int n = n0 + xrow + RPP * i; xb[i] = n < N ? n * K * 2 + xchunk * 16 : -1; }
+    auto xissue = [&](int kt, int stage) {
+      char* As = smem + stage * XSTAGE; char* Bs = As + BM * ROWB;
+#pragma unroll
+      for (int i = 0; i < XA_IT; ++i) dma16(rsA, As + (wave * RPW + RPP * i) * ROWB, xa[i] < 0 ? VN_OOB : (uint32_t)(xa[i] + kt * ROWB));
+#pragma unroll
+      for (int i = 0; i < XB_IT; ++i) dma16(rsB, Bs + (wave * RPW + RPP * i) * ROWB, xb[i] < 0 ? VN_OOB : (uint32_t)(xb[i] + kt * ROWB));
+    };
+    auto xoff = [&](int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); };
+    constexpr int PER = XA_IT + XB_IT;
+    const int nks = K / XBK;
+    half8 af[2][MI], bf[2][NI];
+    auto xload = [&](int buf, int stage, int ks) {
+      const char* As = smem + stage * XSTAGE; const char* Bs = As + BM * ROWB;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[buf][i] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(As + xoff(wm0 + i * 32 + frow, ks * 2 + fhalf)));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[buf][j] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(Bs + xoff(wn0 + j * 32 + frow, ks * 2 + fhalf)));
+    };
+    auto xmma = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
+    };
+    // prologue: XST-1 stages in flight, stage 0 landed + visible, its first fragments in buffer 0
+    for (int t = 0; t < XST - 1 && t < nks; ++t) xissue(t, t);
+    if (nks > XST - 2 && XST > 2) { if (XST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    xload(0, 0, 0);
+    int st = 0;  // LDS slot of the current step
+    for (int s = 0; s < nks; ++s) {
+      int st_new = st + XST - 1; if (st_new >= XST) st_new -= XST;
+      int st_next = st + 1; if (st_next >= XST) st_next -= XST;
+      if (s + XST - 1 < nks) xissue(s + XST - 1, st_new);
+#pragma unroll
+      for (int ks = 0; ks < KSUB; ++ks) {
+        if (ks + 1 < KSUB) {
+          xload((ks + 1) & 1, st, ks + 1);
+          xmma(ks & 1);
+        } else {
+          // the barrier that publishes stage s+1 sits before the LAST MFMA group, so the first fragments of
+          // the next step are fetched under it and the step boundary has no LDS-latency bubble
+          const int younger = min(XST - 2, nks - 2 - s);
+          if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER) : "memory");
+          else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (s + 1 < nks) xload(0, st_next, 0);
+          xmma(ks & 1);
+        }
+      }
+      st = st_next;
+    }
+  }
+#elif STAGES == 2
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

@@ -14,7 +14,16 @@ VARIANTS = {
     "256x256_8w_128x64_fragdb": "-DBM=256 -DBN=256 -DWM=128 -DWN=64 -DFRAGDB",
     "256x256_8w_128x64_fragdb_prio": "-DBM=256 -DBN=256 -DWM=128 -DWN=64 -DFRAGDB -DSETPRIO",
     "256x128_4w_128x64_fragdb": "-DBM=256 -DBN=128 -DWM=128 -DWN=64 -DFRAGDB",
+    "256x256_16w_xpf32x3": "-DBM=256 -DBN=256 -DXPF -DXBK=32 -DXST=3",
+    "256x256_16w_xpf32x4": "-DBM=256 -DBN=256 -DXPF -DXBK=32 -DXST=4",
+    "256x128_8w_xpf64x3": "-DBM=256 -DBN=128 -DXPF -DXBK=64 -DXST=3",
+    "256x128_8w_xpf32x4": "-DBM=256 -DBN=128 -DXPF -DXBK=32 -DXST=4",
+    "128x128_xpf32x4": "-DXPF -DXBK=32 -DXST=4",
+    "128x128_xpf64x3": "-DXPF -DXBK=64 -DXST=3",
 }
+ONLY = os.environ.get("ONLY")
+if ONLY:
+    VARIANTS = {k: v for k, v in VARIANTS.items() if any(o in k for o in ONLY.split(","))}
 def build():
     for name, flags in VARIANTS.items():
         so = os.path.join(HERE, f"lab_{name}.so")
