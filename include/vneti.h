@@ -132,11 +132,13 @@ int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x, long long
 int vneti_layernorm_fwd(const void* x, int x_is_f32, long long ldx, void* y, long long ldy,
                         const float* gamma, const float* beta, float* mean, float* rstd, int rows,
                         int C, float eps, void* stream);
-/* dx (+= dx_accum) ; dx/dx_accum dtype selected by dx_is_f32 */
+/* dx (+= dx_accum) ; dx/dx_accum dtype selected by dx_is_f32.  dx_f16_copy (optional) receives the same
+ * values rounded to f16: the operand of the next dgrad GEMM when dx itself is the f32 residual stream. */
 int vneti_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, const void* x,
                         int x_is_f32, long long ldx, const float* gamma, const float* mean,
                         const float* rstd, void* dx, int dx_is_f32, long long lddx,
-                        const void* dx_accum, long long ldacc, int rows, int C, void* stream);
+                        const void* dx_accum, long long ldacc, void* dx_f16_copy, long long ldcopy,
+                        int rows, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused (flash-style) multi-head attention, head_dim in {40, 64, 80, 160}.

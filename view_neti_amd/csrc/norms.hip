@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
                                                      long long lddx, const void* __restrict__ accum,
-                                                     long long ldacc, int rows, int C) {
+                                                     long long ldacc, half_t* __restrict__ dx16, long long ld16,
+                                                     int rows, int C) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         for (int j = 0; j < 8; ++j) o[j] += a[j];
       }
       ln_store<DXF32>(dx, (long long)row * lddx + c * 8, o);
+      if (dx16) ln_store<false>(dx16, (long long)row * ld16 + c * 8, o);  // f16 copy = next GEMM's operand
     }
   }
 }
@@ -542,15 +544,16 @@ extern "C" int vneti_layernorm_fwd(const void* x, int x_is_f32, long long ldx, v
 extern "C" int vneti_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, const void* x, int x_is_f32,
                                    long long ldx, const float* gamma, const float* mean, const float* rstd,
                                    void* dx, int dx_is_f32, long long lddx, const void* dx_accum, long long ldacc,
-                                   int rows, int C, void* stream) {
+                                   void* dx_f16_copy, long long ldcopy, int rows, int C, void* stream) {
   VN_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  VN_REQUIRE(ldcopy % 8 == 0, "layernorm_bwd: ldcopy % 8 != 0");
   VN_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXC, "layernorm: unsupported C=%d", C);
   VN_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldacc % 8 == 0, "layernorm_bwd: ld % 8 != 0");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(rows, 4));
 #define LN_BWD(A, B, Cc)                                                                                          \
   hipLaunchKernelGGL((ln_bwd_kernel<A, B, Cc>), grid, dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx, \
-                     lddx, dx_accum, ldacc, rows, C)
+                     lddx, dx_accum, ldacc, (half_t*)dx_f16_copy, ldcopy, rows, C)
   int key = (dy_is_f32 ? 4 : 0) | (x_is_f32 ? 2 : 0) | (dx_is_f32 ? 1 : 0);
   switch (key) {
     case 0: LN_BWD(false, false, false); break;

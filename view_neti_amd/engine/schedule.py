@@ -260,8 +260,8 @@ class Schedule:
         self.fwd.append(partial(ops.layernorm_fwd, xv, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], 1e-5))
         return y, rec
 
-    def _ln_bwd(self, rec, dy, dx, accum):
-        ops.layernorm_bwd(dy, rec["x"], rec["gamma"], rec["mean"], rec["rstd"], dx, accum=accum)
+    def _ln_bwd(self, rec, dy, dx, accum, f16_copy=None):
+        ops.layernorm_bwd(dy, rec["x"], rec["gamma"], rec["mean"], rec["rstd"], dx, accum=accum, f16_copy=f16_copy)
 
     def _downsample(self, x: T, Cc, name, w, out_view, h, wd, pad=1):
         """Downsample2D: 3x3 stride-2 conv; pad=1 (UNet) or pad=0 with bottom/right zero padding (VAE)."""

@@ -257,19 +257,20 @@ class TextEngine(Schedule):
                                              self.norm_terms))
         g16 = self._buf((Rt, D))
         dxm = self._buf((Rt, D), torch.float32)
+        # the residual-stream gradient is f32; the dgrad GEMMs want f16 operands: every LayerNorm backward
+        # writes that f16 copy itself, only the very first one (out of text_final_bwd) needs a cast launch
+        bw.append(partial(ops.cast_f32_f16, dx, g16))
         for r in reversed(self.layers):
             ldn = r["ldn"]
             qkv = r["qkv"]
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-            bw.append(partial(ops.cast_f32_f16, dx, g16))
             da = self._tmp("cA", Rt, F)
             bw.append(partial(ops.gemm, g16, r["w2d"], da))
             df1 = self._tmp("cB", Rt, F)
             bw.append(partial(ops.act_bwd, da, r["f1"], df1, r["act"]))
             dn2 = self._tmp("cC", Rt, D)
             bw.append(partial(ops.gemm, df1, r["w1d"], dn2))
-            bw.append(partial(self._ln_bwd, r["ln2"], dn2, dxm, dx))          # dx_mid = LN2'(dn2) + dx_out
-            bw.append(partial(ops.cast_f32_f16, dxm, g16))
+            bw.append(partial(self._ln_bwd, r["ln2"], dn2, dxm, dx, g16))     # dx_mid = LN2'(dn2) + dx_out
             do = self._tmp("cD", Rt, D)
             bw.append(partial(ops.gemm, g16, r["wod"], do))
             delta = self._tmp("cdelta", R * H, L, torch.float32)
@@ -289,7 +290,7 @@ class TextEngine(Schedule):
                               hd, sc_, True))
             dn1 = self._tmp("cC", Rt, D)
             bw.append(partial(ops.gemm, dqkv, r["wqkvd"], dn1))
-            bw.append(partial(self._ln_bwd, r["ln1"], dn1, dx, dxm))          # dx_in = LN1'(dn1) + dx_mid
+            bw.append(partial(self._ln_bwd, r["ln1"], dn1, dx, dxm, g16))     # dx_in = LN1'(dn1) + dx_mid
         self.dx0 = dx
         mo = self.mo
         bw.append(lambda: ops.mapper_bwd(mo.params, self.hidden_mask_obj, mo.norm_scale, self.bo["word"], self.dx0,

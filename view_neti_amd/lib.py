@@ -123,7 +123,7 @@ SIGNATURES = {
                       c_int, c_int, c_int, c_int, c_int, c_vp],
     "layernorm_fwd": [c_vp, c_int, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f, c_vp],
     "layernorm_bwd": [c_vp, c_int, c_ll, c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_vp,
-                      c_ll, c_int, c_int, c_vp],
+                      c_ll, c_vp, c_ll, c_int, c_int, c_vp],
     "attn_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_int,
                  c_f, c_int, c_vp],
     "attn_bwd_delta": [c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_vp],

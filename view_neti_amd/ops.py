@@ -127,12 +127,13 @@ def layernorm_fwd(x, y, gamma, beta, mean, rstd, eps):
             _p(beta), _p(mean), _p(rstd), rows, Cc, eps, stream())
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, accum=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, accum=None, f16_copy=None):
     rows, Cc = x.shape
     _l.call("layernorm_bwd", _p(dy), 1 if dy.dtype == torch.float32 else 0, _ld(dy), _p(x),
             1 if x.dtype == torch.float32 else 0, _ld(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
             1 if dx.dtype == torch.float32 else 0, _ld(dx), _p(accum),
-            _ld(accum) if accum is not None else 0, rows, Cc, stream())
+            _ld(accum) if accum is not None else 0, _p(f16_copy), _ld(f16_copy) if f16_copy is not None else 0,
+            rows, Cc, stream())
 
 
 def attn_fwd(Q, K, Vt, O, lse, Bn, H, Nq, Nk, D, scale, causal, ldvt):
