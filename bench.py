@@ -271,7 +271,9 @@ def main():
         dom = max(rf, key=lambda k: rf[k]["total_ms"])
         d = rf[dom]
         out = {
-            "metric": "TI train steps/sec (SD-1.5 512^2 bs=4 per GPU)", "value": value, "unit": "steps/s",
+            "metric": ("TI train steps/sec (SD-1.5 512^2 bs=4 per GPU)"
+                       if (args.model, args.resolution, args.batch) == ("sd15", 512, 4) else
+                       f"TI train steps/sec ({args.model} {args.resolution}^2 bs={args.batch} per GPU)"), "value": value, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"learnable_mode 0, {args.model} shapes, {args.resolution}x{args.resolution} fp16, "

@@ -81,8 +81,54 @@ def test_dataset_mode0(tmp_path):
     assert -1.0 <= ex["pixel_values"].min() and ex["pixel_values"].max() <= 1.0
     assert ex["input_ids"].shape == (77,) and int(ex["input_ids_placeholder_view"]) == -1
     assert (ex["input_ids"] == ex["input_ids_placeholder_object"]).sum() == 1 and "<toy>" in ex["text"]
-    with pytest.raises(NotImplementedError):
-        TextualInversionDataset(tmp_path / "toys", tk, augmentation_key=7)
+    with pytest.raises(ValueError):
+        TextualInversionDataset(tmp_path / "toys", tk, augmentation_key=9)
+
+
+def test_augmentation_pipelines(tmp_path):
+    """dataset.py:238-316 restated without torchvision: every key keeps the frame size and value range, is
+    reproducible from the torch seed, and each primitive does what its torchvision namesake does."""
+    from view_neti_amd.compat import augment as A
+    _make_images(tmp_path / "toys", ["a.png"], size=(120, 90))
+    tk = HashTokenizer()
+    tk.add_tokens(["<toy>"])
+    base = TextualInversionDataset(tmp_path / "toys", tk, learnable_mode=0, size=64, placeholder_object_token="<toy>")[0]
+    for key in range(1, 9):
+        ds = TextualInversionDataset(tmp_path / "toys", tk, learnable_mode=0, size=64, placeholder_object_token="<toy>",
+                                     augmentation_key=key)
+        torch.manual_seed(3)
+        a = ds[0]["pixel_values"]
+        torch.manual_seed(3)
+        b = ds[0]["pixel_values"]
+        assert a.shape == (3, 64, 64) and torch.equal(a, b) and -1.0 <= a.min() and a.max() <= 1.0
+        diffs = []
+        for seed in range(6):
+            torch.manual_seed(seed)
+            diffs.append((ds[0]["pixel_values"] - base["pixel_values"]).abs().mean().item())
+        assert max(diffs) > 0, f"augmentation_key {key} never changed the image"
+    rng = np.random.RandomState(0)
+    img = Image.fromarray(rng.randint(0, 255, (48, 64, 3), dtype=np.uint8))
+    # hue shift by a whole turn is the identity up to HSV quantisation; +0 is exactly RGB->HSV->RGB
+    assert np.abs(np.asarray(A.adjust_hue(img, 0.0), dtype=int) - np.asarray(img.convert("HSV").convert("RGB"), dtype=int)).max() == 0
+    g = np.asarray(A.to_grayscale3(img))
+    assert (g[..., 0] == g[..., 1]).all() and (g[..., 1] == g[..., 2]).all()
+    # a constant image is a fixed point of the blur (reflect padding, normalised kernel)
+    const = Image.fromarray(np.full((20, 30, 3), 77, dtype=np.uint8))
+    assert (np.asarray(A.gaussian_blur(const)) == 77).all()
+    # sigma in [0.1, 0.2] makes the 5-tap kernel almost a delta: the blur moves pixels by < 1 grey level
+    assert np.abs(np.asarray(A.gaussian_blur(img), dtype=int) - np.asarray(img, dtype=int)).max() <= 1
+    filled = 0
+    for seed in range(5):
+        torch.manual_seed(seed)
+        r = np.asarray(A.random_rotation(img, 10.0, fill=1))
+        assert r.shape == (48, 64, 3)
+        filled += sum(int((r[y, x] == 1).all()) for y in (0, -1) for x in (0, -1))
+    assert filled > 0  # rotated-in corners carry the constant fill value 1
+    torch.manual_seed(0)
+    c = A.random_resized_crop(img, (24, 32), (0.7, 1.3))
+    assert c.size == (32, 24)
+    # scale > 1 can only succeed through the fallback (whole image): still the right output size
+    assert A.random_resized_crop(img, (24, 32), (1.5, 1.6)).size == (32, 24)
 
 
 def test_dataset_dtu_view_mode(tmp_path, monkeypatch):

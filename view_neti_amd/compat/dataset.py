@@ -5,9 +5,9 @@
 
 Covered: learnable_mode 0 (object only; any image folder) and the DTU `dtu-12d` view modes 1-5
 (view tokens generated from the calibration matrices exactly like dataset.py:411-514: the token string
-carries the 12 camera numbers rounded to 4 decimals with '.' -> 'p').  Not covered in this round: the
-torchvision augmentation pipelines (`augmentation_key` 1-8, dataset.py:238-316) — torchvision is
-absent; requesting them raises (SURVEY §8 f3 "next").
+carries the 12 camera numbers rounded to 4 decimals with '.' -> 'p').  The augmentation pipelines
+(`augmentation_key` 1-8, dataset.py:238-316) come from `augment.py` (PIL/numpy restatement: torchvision
+is absent from this image).
 Resizing uses PIL bicubic like the reference (the Coach never overrides `interpolation`).
 """
 from __future__ import annotations
@@ -44,9 +44,20 @@ class TextualInversionDataset(torch.utils.data.Dataset):
         self.dtu_subset = dtu_subset
         self.dtu_preprocess_key = dtu_preprocess_key
         self.caption_strategy = caption_strategy
-        if augmentation_key > 0:
-            raise NotImplementedError("augmentation_key > 0 needs the torchvision pipelines (not available here)")
         self.augmentation_key = augmentation_key
+        self.augmentations = None
+        if augmentation_key > 0:
+            from .augment import build_augmentations
+            if learnable_mode == 0:
+                aug_size = (size, size)
+            elif dtu_preprocess_key == 0:
+                aug_size = (512, 512)
+            elif dtu_preprocess_key == 1:
+                aug_size = (384, 512)  # (height, width): reversed w.r.t. PIL's size (dataset.py:236)
+            else:
+                raise NotImplementedError("augmentation with dtu_preprocess_key 2 is undefined in the reference "
+                                          "(dataset.py:231-236 leaves `size` unset)")
+            self.augmentations = build_augmentations(augmentation_key, aug_size)
         if learnable_mode != 3:
             paths = filter_paths_imgs(sorted(self.data_root.glob("*")))
             if camera_representation == "dtu-12d" and learnable_mode != 0:
@@ -215,6 +226,10 @@ class TextualInversionDataset(torch.utils.data.Dataset):
         image = self._resize(Image.fromarray(arr))
         if self.learnable_mode == 0 and self.flip_p > 0 and torch.rand(1).item() < self.flip_p:
             image = image.transpose(Image.FLIP_LEFT_RIGHT)
+        if self.augmentations is not None:
+            img_size = image.size
+            image = self.augmentations(image)
+            assert image.size == img_size  # dataset.py:731-732
         arr = (np.array(image).astype(np.uint8) / 127.5 - 1.0).astype(np.float32)
         ex["pixel_values"] = torch.from_numpy(arr).permute(2, 0, 1)
         return ex
