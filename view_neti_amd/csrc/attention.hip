@@ -22,6 +22,8 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int TROW64 = 144;  // bytes per row of a [d][64 keys] transposed LDS tile (64*2 + 16 pad)
 constexpr int TROW32 = 80;   // bytes per row of a [d][32 q] transposed LDS tile (32*2 + 16 pad)
+// dK/dV kernel: 32-row query halves per LDS stage (2 where two blocks of 64-row stages still fit one CU's LDS)
+constexpr int DKV_QH(int D) { return D <= 64 ? 2 : 1; }
 
 template <int D>
 struct Cfg {
@@ -540,9 +542,13 @@ template <int D>
 // arch VGPRs (no v_accvgpr copies around the softmax VALU work)
 __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
   using C = Cfg<D>;
-  constexpr int QS_BYTES = 32 * C::ROW;
-  constexpr int QT_BYTES = C::DB * 32 * TROW32;
-  constexpr int STAGE = 2 * QS_BYTES + 2 * QT_BYTES + 256;
+  // query tile per barrier interval: 64 rows (two 32-row halves computed back to back with the same
+  // registers) where two such blocks still fit a CU's LDS, else 32
+  constexpr int QH = DKV_QH(D), QR = 32 * QH;
+  constexpr int TROWQ = QH == 2 ? TROW64 : TROW32;
+  constexpr int QS_BYTES = QR * C::ROW;
+  constexpr int QT_BYTES = C::DB * 32 * TROWQ;
+  constexpr int STAGE = 2 * QS_BYTES + 2 * QT_BYTES + 8 * QR;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -575,19 +581,20 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
   }
   const float c = a.scale * LOG2E;
 
-  constexpr int QIT = (32 * C::DCH + 255) / 256;
-  constexpr int TIT = (D * 4 + 255) / 256;
+  constexpr int QIT = (QR * C::DCH + 255) / 256;
+  constexpr int TCH = QR / 8;  // 16-byte chunks per transposed row
+  constexpr int TIT = (D * TCH + 255) / 256;
   u32x4 qreg[QIT], doreg[QIT], qtreg[TIT], dotreg[TIT];
   float lreg = INFINITY, dreg = 0.f;
 
   auto issue = [&](int qt) {
-    const int q0 = qt * 32;
+    const int q0 = qt * QR;
 #pragma unroll
     for (int i = 0; i < QIT; ++i) {
       int idx = tid + 256 * i;
       int r = idx / C::DCH, cc = idx - r * C::DCH;
       int qq = q0 + r;
-      bool ok = idx < 32 * C::DCH && qq < a.Nq;
+      bool ok = idx < QR * C::DCH && qq < a.Nq;
       uint32_t o1 = ok ? (uint32_t)((((long long)b * a.Nq + qq) * a.ldq + h * D + cc * 8) * 2) : VN_OOB;
       uint32_t o2 = ok ? (uint32_t)((((long long)b * a.Nq + qq) * a.lddo + h * D + cc * 8) * 2) : VN_OOB;
       qreg[i] = vn_buf_load16(rsQ, o1);
@@ -596,9 +603,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < TIT; ++i) {
       int idx = tid + 256 * i;
-      int d = idx >> 2, cc = idx & 3;
+      int d = idx / TCH, cc = idx % TCH;
       int qq = q0 + cc * 8;
-      bool okr = idx < D * 4;
+      bool okr = idx < D * TCH;
       uint32_t o1 = (okr && qq < a.ldqt)
                         ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.ldqt + qq) * 2)
                         : VN_OOB;
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
       qtreg[i] = vn_buf_load16(rsQt, o1);
       dotreg[i] = vn_buf_load16(rsdOt, o2);
     }
-    if (tid < 32) {
+    if (tid < QR) {
       int qq = q0 + tid;
       if (qq < a.Nq) {
         lreg = a.lse_in[((long long)b * a.H + h) * a.Nq + qq] * LOG2E;
@@ -625,12 +632,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
     char* Qts = Qs + 2 * QS_BYTES;
     char* dOts = Qts + QT_BYTES;
     float* lses = reinterpret_cast<float*>(dOts + QT_BYTES);
-    float* dels = lses + 32;
+    float* dels = lses + QR;
 #pragma unroll
     for (int i = 0; i < QIT; ++i) {
       int idx = tid + 256 * i;
       int r = idx / C::DCH, cc = idx - r * C::DCH;
-      if (idx < 32 * C::DCH) {
+      if (idx < QR * C::DCH) {
         *reinterpret_cast<u32x4*>(Qs + r * C::ROW + cc * 16) = qreg[i];
         *reinterpret_cast<u32x4*>(dOs + r * C::ROW + cc * 16) = doreg[i];
       }
@@ -638,13 +645,13 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < TIT; ++i) {
       int idx = tid + 256 * i;
-      int d = idx >> 2, cc = idx & 3;
-      if (idx < D * 4) {
-        *reinterpret_cast<u32x4*>(Qts + d * TROW32 + cc * 16) = qtreg[i];
-        *reinterpret_cast<u32x4*>(dOts + d * TROW32 + cc * 16) = dotreg[i];
+      int d = idx / TCH, cc = idx % TCH;
+      if (idx < D * TCH) {
+        *reinterpret_cast<u32x4*>(Qts + d * TROWQ + cc * 16) = qtreg[i];
+        *reinterpret_cast<u32x4*>(dOts + d * TROWQ + cc * 16) = dotreg[i];
       }
     }
-    if (tid < 32) {
+    if (tid < QR) {
       lses[tid] = lreg;
       dels[tid] = dreg;
     }
@@ -659,10 +666,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
       dv[i][e] = 0.f;
     }
 
-  const int nqt_all = cdiv_dev(a.Nq, 32);
+  const int nqt_all = cdiv_dev(a.Nq, QR);
   const int per = cdiv_dev(nqt_all, a.qsplit);
   const int nqt = min(nqt_all, (qs + 1) * per);
-  const int qt0 = max(qs * per, a.causal ? min(kb0 / 32, nqt_all) : 0);
+  const int qt0 = max(qs * per, a.causal ? min(kb0 / QR, nqt_all) : 0);
 
   if (qt0 < nqt) issue(qt0);
   __syncthreads();
@@ -670,54 +677,57 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
   __syncthreads();
   for (int qt = qt0; qt < nqt; ++qt) {
     if (qt + 1 < nqt) issue(qt + 1);
-    const int q0 = qt * 32;
+    const int q0 = qt * QR;
     const char* Qs = smem + ((qt - qt0) & 1) * STAGE;
     const char* dOs = Qs + QS_BYTES;
     const char* Qts = Qs + 2 * QS_BYTES;
     const char* dOts = Qts + QT_BYTES;
     const float* lses = reinterpret_cast<const float*>(dOts + QT_BYTES);
-    const float* dels = lses + 32;
+    const float* dels = lses + QR;
 
-    f32x16 s, dp;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      s[e] = 0.f;
-      dp[e] = 0.f;
-    }
+    for (int hq = 0; hq < QH; ++hq) {
+      f32x16 s, dp;
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      const int off = l31 * C::ROW + (ks * 2 + h2) * 16;
-      half8 qfr = as_half8(*reinterpret_cast<const u32x4*>(Qs + off));
-      half8 dofr = as_half8(*reinterpret_cast<const u32x4*>(dOs + off));
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dofr, vf[ks], dp, 0, 0, 0);
-    }
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      f32x4 l4 = *reinterpret_cast<const f32x4*>(&lses[8 * qd + 4 * h2]);
-      f32x4 d4 = *reinterpret_cast<const f32x4*>(&dels[8 * qd + 4 * h2]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * qd + e;
-        float p = fast_exp2(s[r] * c - l4[e]);
-        if (a.causal) {
-          int qq = q0 + 8 * qd + 4 * h2 + e;
-          if (key > qq) p = 0.f;
-        }
-        s[r] = p;
-        dp[r] = p * (dp[r] - d4[e]);
+      for (int e = 0; e < 16; ++e) {
+        s[e] = 0.f;
+        dp[e] = 0.f;
       }
-    }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      half8 pf = cvt8(s, j);
-      half8 dsf = cvt8(dp, j);
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const int off = (hq * 32 + l31) * C::ROW + (ks * 2 + h2) * 16;
+        half8 qfr = as_half8(*reinterpret_cast<const u32x4*>(Qs + off));
+        half8 dofr = as_half8(*reinterpret_cast<const u32x4*>(dOs + off));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dofr, vf[ks], dp, 0, 0, 0);
+      }
 #pragma unroll
-      for (int db = 0; db < C::DB; ++db) {
-        half8 dot = load_tfrag(dOts, TROW32, db * 32 + l31, 16 * j + 4 * h2);
-        half8 qtf = load_tfrag(Qts, TROW32, db * 32 + l31, 16 * j + 4 * h2);
-        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf, dv[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf, dk[db], 0, 0, 0);
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 l4 = *reinterpret_cast<const f32x4*>(&lses[hq * 32 + 8 * qd + 4 * h2]);
+        f32x4 d4 = *reinterpret_cast<const f32x4*>(&dels[hq * 32 + 8 * qd + 4 * h2]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * qd + e;
+          float p = fast_exp2(s[r] * c - l4[e]);
+          if (a.causal) {
+            int qq = q0 + hq * 32 + 8 * qd + 4 * h2 + e;
+            if (key > qq) p = 0.f;
+          }
+          s[r] = p;
+          dp[r] = p * (dp[r] - d4[e]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        half8 pf = cvt8(s, j);
+        half8 dsf = cvt8(dp, j);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+          half8 dot = load_tfrag(dOts, TROWQ, db * 32 + l31, hq * 32 + 16 * j + 4 * h2);
+          half8 qtf = load_tfrag(Qts, TROWQ, db * 32 + l31, hq * 32 + 16 * j + 4 * h2);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf, dk[db], 0, 0, 0);
+        }
       }
     }
     if (qt + 1 < nqt) commit((qt + 1 - qt0) & 1);
@@ -927,7 +937,7 @@ extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, 
   a.scale = scale;
   a.causal = causal;
   // few key blocks (cross-attention: Nk = 77) => split the query range so the chip is filled
-  const int nkb = cdiv(Nk, 128), nqt = cdiv(Nq, 32);
+  const int nkb = cdiv(Nk, 128), nqt = cdiv(Nq, 32 * DKV_QH(D));
   long long blocks = (long long)nkb * H * Bn;
   int qsplit = 1;
   if (ws && !causal && blocks < 256 && nqt >= 8) {
