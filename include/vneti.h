@@ -217,6 +217,23 @@ int vneti_sample_add_noise(const void* moments, long long ldm, const float* eps,
                            const float* alphas_cumprod, float scaling, int v_prediction,
                            float* latents, float* noisy, float* target, int Bn, int Lc, int HW,
                            void* stream);
+/* Inference (sd_pipeline_call.py:72-103): classifier-free guidance on the CFG-batched UNet output (rows
+ * [0,B*HW) unconditional, [B*HW,2B*HW) conditional) and one sampler step in data-prediction form
+ *   e = u + g (c - u);  x0 = (x - sigma_t e)/alpha_t  (epsilon)  |  alpha_t x - sigma_t e  (v_prediction)
+ *   x <- cx x + c0 x0 + c1 m_prev;  m_prev <- x0;  x_in[2B] <- x (both CFG halves of the next UNet input)
+ * which covers DPM-Solver++(2M) (DPMSolverMultistepScheduler, training/validate.py:568) and DDIM (eta = 0);
+ * the per-step scalars come from the host (view_neti_amd/engine/infer.py::step_coefficients).
+ * x, m_prev: f32 NCHW [B][Lc][HW]; x_in: f32 NCHW [2B][Lc][HW]; pred: f16 NHWC. */
+int vneti_cfg_sampler_step(const void* pred, long long ldp, float* x, float* m_prev, float* x_in, int Bn,
+                           int Lc, int HW, float guidance, float alpha_t, float sigma_t, float cx,
+                           float c0, float c1, int v_prediction, void* stream);
+/* AutoencoderKL.post_quant_conv on the latents scaled by 1/scaling_factor (pipeline.decode_latents):
+ * NCHW f32, out[b][o][p] = bias[o] + sum_c W[o][c] x[b][c][p] * in_scale; channel counts <= 8 */
+int vneti_conv1x1_nchw_f32(const float* x, const float* W, const float* bias, float* out, int Bn, int Ci,
+                           int Co, int HW, float in_scale, void* stream);
+/* pipeline.decode_latents tail (sd_pipeline_call.py:115): (img/2 + 0.5).clamp(0,1), NHWC f16 -> f32 [n_pix][ch] */
+int vneti_image_postprocess(const void* img, long long ldi, float* out, long long n_pix, int channels,
+                            void* stream);
 /* F.mse_loss(pred.float(), target.float()) partial sum (+= into loss_sum[0]) and the scaled
  * gradient seed dpred = 2 (pred - target) / N * loss_scale[0]  (training/coach.py:211-214) */
 int vneti_mse_loss_grad(const void* pred, long long ldp, const float* target, void* dpred,

@@ -186,6 +186,17 @@ def neti_text_encoder(w: W, cfg, input_ids, placeholder_object, word_object, byp
     return F.layer_norm(last, (D,), lnw, lnb, cfg.eps), with_bypass
 
 
+def clip_plain(w: W, cfg, input_ids: torch.Tensor) -> torch.Tensor:
+    """the plain `text_encoder(input_ids=...)[0]` path (NeTICLIPTextTransformer.forward without a
+    NeTIBatch; sd_pipeline_call.py:35-39 uses it for the negative prompt): embeddings -> encoder ->
+    final_layer_norm."""
+    x = neti_embeddings(w["text_model.embeddings.token_embedding.weight"],
+                        w["text_model.embeddings.position_embedding.weight"], input_ids, None, None)
+    last = clip_encoder(w, cfg, x)
+    return F.layer_norm(last, (last.shape[-1],), w["text_model.final_layer_norm.weight"],
+                        w["text_model.final_layer_norm.bias"], cfg.eps)
+
+
 # ------------------------------------------------------------------------------------------
 # reference-owned: XTI attention processor
 # ------------------------------------------------------------------------------------------
@@ -434,3 +445,100 @@ def adamw_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2):
     mhat = m / (1 - b1 ** step)
     vhat = v / (1 - b2 ** step)
     return p - lr * mhat / (vhat.sqrt() + eps), m, v
+
+# ------------------------------------------------------------------------------------------
+# inference path: AutoencoderKL.decode, DPM-Solver++(2M) / DDIM, sd_pipeline_call
+# third-party pieces follow diffusers 0.14 — PARITY UNPINNED (diffusers is not installable here)
+# ------------------------------------------------------------------------------------------
+def vae_decode(w: W, cfg, z: torch.Tensor) -> torch.Tensor:
+    """z (B,latent,h,w) already divided by the scaling factor -> image (B,3,8h,8w) in ~[-1,1]
+    (`pipeline.decode_latents`, sd_pipeline_call.py:115: post_quant_conv -> Decoder)."""
+    G, eps = cfg.norm_num_groups, cfg.norm_eps
+    boc = list(reversed(cfg.block_out_channels))
+    h = F.conv2d(z, w["post_quant_conv.weight"], w["post_quant_conv.bias"])
+    h = F.conv2d(h, w["decoder.conv_in.weight"], w["decoder.conv_in.bias"], padding=1)
+    h = _resnet(w, "decoder.mid_block.resnets.0.", h, None, G, eps)
+    a = "decoder.mid_block.attentions.0."
+    B, C, H, Wd = h.shape
+    n = F.group_norm(h, G, w[a + "group_norm.weight"], w[a + "group_norm.bias"], eps)
+    n = n.view(B, C, H * Wd).transpose(1, 2)
+    q = F.linear(n, w[a + "query.weight"], w[a + "query.bias"])
+    k = F.linear(n, w[a + "key.weight"], w[a + "key.bias"])
+    v = F.linear(n, w[a + "value.weight"], w[a + "value.bias"])
+    probs = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(C), -1)
+    o = F.linear(probs @ v, w[a + "proj_attn.weight"], w[a + "proj_attn.bias"])
+    h = o.transpose(1, 2).reshape(B, C, H, Wd) + h
+    h = _resnet(w, "decoder.mid_block.resnets.1.", h, None, G, eps)
+    for i in range(len(boc)):
+        for j in range(cfg.layers_per_block + 1):
+            h = _resnet(w, f"decoder.up_blocks.{i}.resnets.{j}.", h, None, G, eps)
+        if i < len(boc) - 1:
+            p = f"decoder.up_blocks.{i}.upsamplers.0.conv."
+            h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), w[p + "weight"], w[p + "bias"], padding=1)
+    h = F.silu(F.group_norm(h, G, w["decoder.conv_norm_out.weight"], w["decoder.conv_norm_out.bias"], eps))
+    return F.conv2d(h, w["decoder.conv_out.weight"], w["decoder.conv_out.bias"], padding=1)
+
+
+def inference_timesteps(kind: str, num_steps: int, num_train: int = 1000):
+    """DPMSolverMultistepScheduler.set_timesteps / DDIMScheduler.set_timesteps (steps_offset=1 for SD)."""
+    import numpy as np
+    if kind == "dpm++2m":
+        return [int(t) for t in np.linspace(0, num_train - 1, num_steps + 1).round()[::-1][:-1].astype(np.int64)]
+    if kind == "ddim":
+        ratio = num_train // num_steps
+        return [int(t) for t in ((np.arange(0, num_steps) * ratio).round()[::-1].astype(np.int64) + 1)]
+    raise ValueError(kind)
+
+
+def step_coefficients(kind: str, ac: torch.Tensor, timesteps, i: int):
+    """One sampler step written as x_prev = cx*x + c0*x0(t_i) + c1*x0(t_{i-1}) on the data prediction
+    x0 (DPM-Solver++ `convert_model_output`; for DDIM with eta=0 the same algebra with c1 = 0).
+    Returns (cx, c0, c1, alpha_t, sigma_t) as python floats; ac = alphas_cumprod (f32)."""
+    ac = ac.double()
+    t = timesteps[i]
+    al, sg = ac.sqrt(), (1 - ac).sqrt()
+    if kind == "ddim":
+        ratio = 1000 // len(timesteps)
+        tp = t - ratio
+        a_t = ac[t]
+        a_p = ac[tp] if tp >= 0 else ac[0]  # set_alpha_to_one=False in the SD scheduler configs
+        r = ((1 - a_p) / (1 - a_t)).sqrt()
+        return float(r), float(a_p.sqrt() - r * a_t.sqrt()), 0.0, float(al[t]), float(sg[t])
+    lam = al.log() - sg.log()
+    n = len(timesteps)
+    tp = 0 if i == n - 1 else timesteps[i + 1]
+    h = lam[tp] - lam[t]
+    cx = sg[tp] / sg[t]
+    base = -al[tp] * (torch.exp(-h) - 1.0)
+    first_order = i == 0 or (i == n - 1 and n < 15)  # lower_order_nums < 1, lower_order_final
+    if first_order:
+        return float(cx), float(base), 0.0, float(al[t]), float(sg[t])
+    h0 = lam[t] - lam[timesteps[i - 1]]
+    r0 = h0 / h
+    # D0 = m0, D1 = (m0 - m1)/r0:  x = cx*x + base*D0 + 0.5*base*D1
+    return float(cx), float(base * (1 + 0.5 / r0)), float(-0.5 * base / r0), float(al[t]), float(sg[t])
+
+
+def sd_pipeline_call(sd_cfg, unet_w, vae_dec_w, prompt_embeds, negative_embeds, latents, kind="dpm++2m",
+                     num_inference_steps=50, guidance_scale=7.5):
+    """sd_pipeline_call.py:8-133: per-step NeTI context dicts (`prompt_embeds[i]`), an unconditional
+    embedding used for K and V of every layer, CFG, sampler step, decode, (x/2+0.5).clamp(0,1).
+    prompt_embeds: list (one per timestep) of XTI context dicts; negative_embeds (B,77,D)."""
+    ac = alphas_cumprod(sd_cfg.ddpm)
+    ts = inference_timesteps(kind, num_inference_steps, sd_cfg.ddpm.num_train_timesteps)
+    x = latents.clone()
+    m_prev = torch.zeros_like(x)
+    B = x.shape[0]
+    for i, t in enumerate(ts):
+        tt = torch.full((B,), t, dtype=torch.int64)
+        eu = unet_forward(unet_w, sd_cfg.unet, x, tt, negative_embeds)
+        hs = dict(prompt_embeds[i])
+        hs["this_idx"] = 0
+        ec = unet_forward(unet_w, sd_cfg.unet, x, tt, hs)
+        e = eu + guidance_scale * (ec - eu)
+        cx, c0, c1, a_t, s_t = step_coefficients(kind, ac, ts, i)
+        x0 = (x - s_t * e) / a_t if sd_cfg.ddpm.prediction_type == "epsilon" else a_t * x - s_t * e
+        x = cx * x + c0 * x0 + c1 * m_prev
+        m_prev = x0
+    img = vae_decode(vae_dec_w, sd_cfg.vae, x / sd_cfg.vae.scaling_factor)
+    return (img / 2 + 0.5).clamp(0, 1), x

@@ -1,0 +1,110 @@
+"""Inference path on the GPU vs the CPU oracle: VAE decoder, the CFG + sampler step, and the whole
+`sd_pipeline_call` loop (per-step NeTI contexts -> CFG-batched UNet -> DPM-Solver++(2M)/DDIM -> decode)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+@pytest.mark.parametrize("B,h,w", [(1, 8, 8), (2, 8, 16)])
+def test_vae_decoder_tiny(B, h, w):
+    from oracle import sd_ref as R
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.vae import VAEDecoderEngine
+    cfg = sc.tiny().vae
+    wts = synth.vae_decoder_weights(cfg)
+    r16 = {k: (v.half().float() if v.dim() >= 2 and not k.startswith("post_quant") else v) for k, v in wts.items()}
+    eng = VAEDecoderEngine(cfg, wts, B, h, w)
+    z = synth.gaussian((B, 4, h, w), 21) * cfg.scaling_factor
+    eng.z_in.copy_(z)
+    eng.forward()
+    torch.cuda.synchronize()
+    ref = R.vae_decode(r16, cfg, z / cfg.scaling_factor)
+    ref_img = (ref / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
+    raw = eng.rgb[:, :3].float().cpu().view(B, 8 * h, 8 * w, 3)
+    e_raw = _rel(raw, ref.permute(0, 2, 3, 1))
+    e_img = (eng.image.cpu() - ref_img).abs().max().item()
+    print(f"[vae decoder tiny {B}x{h}x{w}] raw rel {e_raw:.3e} (std {ref.std():.3f}); image max abs {e_img:.3e}; "
+          f"{len(eng.fwd)} launches")
+    assert eng.image.shape == (B, 8 * h, 8 * w, 3) and e_raw < 5e-3 and e_img < 2e-2
+    assert 0.0 <= float(eng.image.min()) and float(eng.image.max()) <= 1.0
+
+
+@pytest.mark.parametrize("vpred", [False, True])
+def test_cfg_sampler_step_kernel(vpred):
+    from view_neti_amd import ops
+    B, Lc, HW = 2, 4, 96
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randn(2 * B * HW, 8, generator=g).half()
+    x, m = torch.randn(B, Lc, HW, generator=g), torch.randn(B, Lc, HW, generator=g)
+    xd, md = x.cuda(), m.cuda()
+    x_in = torch.zeros(2 * B, Lc, HW, device="cuda")
+    gs, a_t, s_t, cx, c0, c1 = 7.5, 0.8, 0.6, 0.93, 0.11, -0.03
+    ops.cfg_sampler_step(pred.cuda()[:, :Lc], xd, md, x_in, B, Lc, HW, gs, a_t, s_t, cx, c0, c1, vpred)
+    p = pred[:, :Lc].float().view(2, B, HW, Lc).permute(0, 1, 3, 2)
+    e = p[0] + gs * (p[1] - p[0])
+    x0 = a_t * x - s_t * e if vpred else (x - s_t * e) / a_t
+    xn = cx * x + c0 * x0 + c1 * m
+    assert torch.allclose(xd.cpu(), xn, atol=2e-5, rtol=1e-5) and torch.allclose(md.cpu(), x0, atol=2e-5, rtol=1e-5)
+    assert torch.equal(x_in[:B], xd) and torch.equal(x_in[B:], xd)
+
+
+@pytest.mark.parametrize("cfg_name,kind,steps", [("tiny", "dpm++2m", 6), ("tiny21", "ddim", 5)])
+def test_pipeline_matches_oracle(cfg_name, kind, steps):
+    """whole generation on the tiny SD families (epsilon / v-prediction), object + view mappers, vs the oracle's
+    restatement of sd_pipeline_call: final latents and decoded image."""
+    from oracle import sd_ref as R
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.infer import InferenceEngine, inference_timesteps, step_coefficients
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    cfg = sc.CONFIGS[cfg_name]()
+    B, H, W = 2, 64, 64
+    D = cfg.clip.hidden_size
+    uw, dw, cw = synth.unet_weights(cfg.unet), synth.vae_decoder_weights(cfg.vae), synth.clip_weights(cfg.clip)
+    gen = torch.Generator().manual_seed(9)
+    mk = lambda: {k: v + 0.05 * torch.randn(v.shape, generator=gen) for k, v in init_mapper_state(64, 64, D).items()}
+    sdo, sdv = mk(), mk()
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    w_enc_v = fourier_frequencies([0.03, 2.0] + [0.5] * 12, 64, 0)
+    eng = InferenceEngine(cfg, uw, dw, cw, B, H, W, sdo, w_enc, 0.4, 0.2, mapper_view=sdv, w_enc_view=w_enc_v,
+                          norm_scale_view=0.35, alpha_view=0.3)
+    ph, phv = cfg.clip.vocab_size - 3, cfg.clip.vocab_size - 4
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size, view_placeholder_id=phv)
+    neg = synth.input_ids(1, ph, cfg.clip.vocab_size)
+    neg[neg == ph] = 7  # a prompt without any placeholder
+    vparams = synth.gaussian((B, 12), 9).clamp(-1, 1)
+    lat = synth.gaussian((B, 4, H // 8, W // 8), 17)
+    eng.set_negative_prompt(neg)
+    eng.set_prompt(ids, torch.full((B,), ph), torch.full((B,), phv), vparams)
+    gs = 5.0
+    img = eng.generate(lat, steps, gs, kind).cpu()
+    x_gpu = eng.x.cpu()
+    # ---- oracle ----
+    assert inference_timesteps(kind, steps) == R.inference_timesteps(kind, steps)
+    ac = R.alphas_cumprod(cfg.ddpm)
+    ts = R.inference_timesteps(kind, steps)
+    for i in range(steps):
+        a, b = step_coefficients(kind, ac, ts, i), R.step_coefficients(kind, ac, ts, i)
+        assert all(abs(p - q) < 1e-9 for p, q in zip(a, b))
+    r16 = lambda d: {k: (v.half().float() if v.dim() >= 2 and "embedding" not in k and not k.startswith("post_quant")
+                         else v) for k, v in d.items()}
+    uwr, dwr, cwr = r16(uw), r16(dw), r16(cw)
+    with torch.no_grad():
+        negative = R.clip_plain(cwr, cfg.clip, neg.expand(B, -1)).half().float()
+        embeds = []
+        view = dict(p=sdv, w_enc=w_enc_v, norm_scale=0.35, placeholder=torch.full((B,), phv), params=vparams, alpha=0.3)
+        for t in ts:
+            hs = R.text_conditioning(cwr, cfg.clip, sdo, w_enc, 0.4, ids, torch.full((B,), ph),
+                                     torch.full((B,), t), alpha=0.2, n_layers=cfg.unet.n_cross_layers, view=view)
+            embeds.append({k: (v.half().float() if k != "this_idx" else v) for k, v in hs.items()})
+        ref_img, ref_x = R.sd_pipeline_call(cfg, uwr, dwr, embeds, negative, lat, kind, steps, gs)
+    ex = _rel(x_gpu, ref_x)
+    ei = (img - ref_img.permute(0, 2, 3, 1)).abs().mean().item()
+    print(f"[pipeline {cfg_name} {kind} x{steps}] final latents rel {ex:.3e}; image mean abs err {ei:.3e} "
+          f"(image std {ref_img.std():.3f})")
+    assert ex < 2e-2 and ei < 1e-2

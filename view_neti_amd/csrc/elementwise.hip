@@ -215,6 +215,54 @@ __global__ void sample_add_noise_kernel(const half_t* moments, long long ldm, co
   target[gid] = vpred ? (sa * n - sb * z) : n;
 }
 
+// ---- inference: classifier-free guidance + one sampler step (sd_pipeline_call.py:72-103) ---------------
+// pred: NHWC f16 [2*B*HW][ldp], rows [0,B*HW) unconditional, [B*HW,2*B*HW) conditional.  x, m_prev: NCHW f32
+// [B][Lc][HW].  e = u + g (c-u);  x0 = (x - sigma_t e)/alpha_t (epsilon) or alpha_t x - sigma_t e (v);
+// x <- cx x + c0 x0 + c1 m_prev;  m_prev <- x0;  x_in (NCHW f32 [2B][Lc][HW], the UNet input) <- x in both halves.
+__global__ void cfg_sampler_step_kernel(const half_t* pred, long long ldp, float* x, float* m_prev, float* x_in,
+                                        int Bn, int Lc, int HW, float guidance, float alpha_t, float sigma_t, float cx,
+                                        float c0, float c1, int vpred) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = Bn * Lc * HW;
+  if (gid >= total) return;
+  int p = gid % HW;
+  int c = (gid / HW) % Lc;
+  int b = gid / (HW * Lc);
+  float u = (float)pred[((long long)b * HW + p) * ldp + c];
+  float cnd = (float)pred[((long long)(Bn + b) * HW + p) * ldp + c];
+  float e = u + guidance * (cnd - u);
+  float xv = x[gid];
+  float x0 = vpred ? (alpha_t * xv - sigma_t * e) : (xv - sigma_t * e) / alpha_t;
+  float xn = cx * xv + c0 * x0 + c1 * m_prev[gid];
+  x[gid] = xn;
+  m_prev[gid] = x0;
+  x_in[gid] = xn;
+  x_in[(long long)total + gid] = xn;
+}
+// tiny 1x1 conv on NCHW f32 latents (AutoencoderKL.post_quant_conv after the 1/scaling_factor of
+// pipeline.decode_latents): out[b][o][p] = bias[o] + sum_c W[o][c] * x[b][c][p] * in_scale,  C <= 8
+__global__ void conv1x1_nchw_kernel(const float* x, const float* W, const float* bias, float* out, int Bn, int Ci,
+                                    int Co, int HW, float in_scale) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= Bn * Co * HW) return;
+  int p = gid % HW;
+  int o = (gid / HW) % Co;
+  int b = gid / (HW * Co);
+  float acc = bias ? bias[o] : 0.f;
+  for (int c = 0; c < Ci; ++c) acc += W[o * Ci + c] * x[((long long)b * Ci + c) * HW + p] * in_scale;
+  out[gid] = acc;
+}
+// decoder output NHWC f16 [B*HW][ldi] (3 channels) -> (v/2 + 0.5).clamp(0,1) as f32 [B][HW][3]
+// (pipeline.decode_latents, sd_pipeline_call.py:115)
+__global__ void image_postprocess_kernel(const half_t* img, long long ldi, float* out, long long n_pix, int ch) {
+  long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_pix * ch) return;
+  long long p = gid / ch;
+  int c = (int)(gid - p * ch);
+  float v = (float)img[p * ldi + c] * 0.5f + 0.5f;
+  out[gid] = fminf(fmaxf(v, 0.f), 1.f);
+}
+
 // ---- MSE loss + gradient seed -------------------------------------------------------------------
 // pred: NHWC f16 [B*HW][ldp] (Lc channels used); target NCHW f32.  loss_sum += sum (p-t)^2 (one
 // atomic per block); dpred (NHWC f16) = 2*(p-t)/N * loss_scale[0].
@@ -440,6 +488,34 @@ extern "C" int vneti_sample_add_noise(const void* moments, long long ldm, const 
                      eps, noise, (const long long*)timesteps, alphas_cumprod, scaling, v_prediction, latents, noisy,
                      target, Bn, Lc, HW);
   return vneti_check_launch("sample_add_noise");
+}
+
+extern "C" int vneti_cfg_sampler_step(const void* pred, long long ldp, float* x, float* m_prev, float* x_in, int Bn,
+                                      int Lc, int HW, float guidance, float alpha_t, float sigma_t, float cx, float c0,
+                                      float c1, int v_prediction, void* stream) {
+  VN_REQUIRE(pred && x && m_prev && x_in && Bn > 0 && Lc > 0 && HW > 0 && alpha_t > 0.f,
+             "cfg_sampler_step: bad arguments");
+  int n = Bn * Lc * HW;
+  hipLaunchKernelGGL(cfg_sampler_step_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const half_t*)pred, ldp, x,
+                     m_prev, x_in, Bn, Lc, HW, guidance, alpha_t, sigma_t, cx, c0, c1, v_prediction);
+  return vneti_check_launch("cfg_sampler_step");
+}
+
+extern "C" int vneti_conv1x1_nchw_f32(const float* x, const float* W, const float* bias, float* out, int Bn, int Ci,
+                                      int Co, int HW, float in_scale, void* stream) {
+  VN_REQUIRE(x && W && out && Bn > 0 && Ci > 0 && Ci <= 8 && Co > 0 && Co <= 8 && HW > 0, "conv1x1_nchw: bad arguments");
+  int n = Bn * Co * HW;
+  hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, x, W, bias, out, Bn, Ci, Co, HW,
+                     in_scale);
+  return vneti_check_launch("conv1x1_nchw");
+}
+
+extern "C" int vneti_image_postprocess(const void* img, long long ldi, float* out, long long n_pix, int channels,
+                                       void* stream) {
+  VN_REQUIRE(img && out && n_pix > 0 && channels > 0 && channels <= ldi, "image_postprocess: bad arguments");
+  hipLaunchKernelGGL(image_postprocess_kernel, dim3((unsigned)cdivl(n_pix * channels, 256)), dim3(256), 0, ST,
+                     (const half_t*)img, ldi, out, n_pix, channels);
+  return vneti_check_launch("image_postprocess");
 }
 
 extern "C" int vneti_mse_loss_grad(const void* pred, long long ldp, const float* target, void* dpred,

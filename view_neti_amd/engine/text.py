@@ -128,6 +128,23 @@ class TextEngine(Schedule):
             else:
                 mask.fill_(1.0)  # eval: no dropout (truncation_idx is an inference-only knob)
 
+    def set_truncation(self, truncation_idx: Optional[int]):
+        """inference-time truncation of the mapper's hidden vector (`truncation_idx`, neti_mapper.py:409-411):
+        hidden[idx:] = 0 for every call; None restores the full vector."""
+        for name, m in (("hidden_mask_obj", self.mo), ("hidden_mask_view", self.mv)):
+            if m is None:
+                continue
+            mask = getattr(self, name)
+            if truncation_idx is None:
+                if mask is not None:
+                    mask.fill_(1.0)
+                continue
+            if mask is None:
+                mask = torch.ones((self.R, m.hidden), dtype=torch.float32, device=self.dev)
+                setattr(self, name, mask)
+            mask.fill_(1.0)
+            mask[:, truncation_idx:] = 0.0
+
     # ------------------------------------------------------------------ batch plumbing
     def set_batch(self, input_ids: torch.Tensor, placeholder_object: torch.Tensor,
                   placeholder_view: Optional[torch.Tensor] = None, view_params: Optional[torch.Tensor] = None):
@@ -144,11 +161,16 @@ class TextEngine(Schedule):
                 raise ValueError("each prompt must contain its placeholder token exactly once")
             return locs.float().argmax(1).to(torch.int32)
 
-        po = positions(placeholder_object)
+        if bool((placeholder_object.cpu() == -1).all()):
+            # no learned object token in the prompt (mode 1 captions, the negative prompt of inference):
+            # position -1 never matches, so the rows keep their vocabulary embedding and there is no bypass
+            po = torch.full((B,), -1, dtype=torch.int32)
+        else:
+            po = positions(placeholder_object)
         self.ids.copy_(ids)
         self.pos_obj.copy_(po)
         base = (torch.arange(nl).view(nl, 1) * B + torch.arange(B).view(1, B)) * L
-        self.rows_obj.copy_((base + po.view(1, B)).reshape(-1).to(torch.int32))
+        self.rows_obj.copy_((base + po.clamp(min=0).view(1, B)).reshape(-1).to(torch.int32))
         if self.mv is not None:
             if placeholder_view is None or bool((placeholder_view == -1).all()):
                 self.pos_view.fill_(-1)
@@ -186,9 +208,9 @@ class TextEngine(Schedule):
             mv = self.mv
             self.bv = self._mapper_bufs(mv, 2 + self.view_params.shape[1])
             f.append(partial(ops.mapper_inputs, self.timesteps, self.view_params, self.bv["data"], nl, B))
-            f.append(partial(ops.mapper_fwd, mv.params, self.bv["data"], mv.w_enc, self.hidden_mask_view,
-                             mv.norm_scale, self.bv["word"], self.bv["byp"], self.bv["save"], R, mv.enc_dim, mv.hidden,
-                             D, True))
+            f.append(lambda: ops.mapper_fwd(mv.params, self.bv["data"], mv.w_enc, self.hidden_mask_view,
+                                            mv.norm_scale, self.bv["word"], self.bv["byp"], self.bv["save"], R,
+                                            mv.enc_dim, mv.hidden, D, True))
         x = self._buf((Rt, D), torch.float32)
         f.append(partial(ops.text_embed, self.tok_emb, self.pos_emb, self.ids, self.pos_obj, self.bo["word"],
                          self.pos_view, self.bv["word"] if self.bv else None, x, nl, B, L, D))

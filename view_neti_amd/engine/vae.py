@@ -105,3 +105,72 @@ class VAEEncoderEngine(Schedule):
         out = T(self._buf((M, Cc)), need_grad=False)
         self.fwd.append(partial(ops.gemm, o, wo, out.v, bias=bo, resid=x.v))
         return out
+
+
+class VAEDecoderEngine(VAEEncoderEngine):
+    """AutoencoderKL.decode as a forward-only launch schedule (inference path, SURVEY §8 f1;
+    `pipeline.decode_latents`, sd_pipeline_call.py:115): latents/scaling -> post_quant_conv -> conv_in -> mid
+    (resnet, single-head attention, resnet) -> 4 up blocks of 3 resnets (+ nearest-2x upsample fused into the
+    following 3x3 conv's loader) -> GN+SiLU -> conv_out -> (x/2+0.5).clamp(0,1).
+    Input: `z_in` f32 NCHW [B,latent,h,w] (the sampler's latents); output: `image` f32 [B, 8h, 8w, 3] in [0,1]."""
+
+    def __init__(self, cfg: sc.VAEConfig, weights: Dict[str, torch.Tensor], batch: int, h: int, w: int,
+                 device: str = "cuda", autotune: bool = True):
+        Schedule.__init__(self, batch, cfg.norm_num_groups, cfg.norm_eps, device, need_backward=False)
+        self.cfg = cfg
+        self.h, self.w = h, w
+        nlev = len(cfg.block_out_channels)
+        self.H, self.W = h << (nlev - 1), w << (nlev - 1)
+        lc = cfg.latent_channels
+        self.z_in = self._buf((batch, lc, h, w), torch.float32)
+        self.image = self._buf((batch, self.H, self.W, cfg.in_channels), torch.float32)
+        self._build_decoder(weights)
+        if autotune:
+            self.autotune()
+        self.bind_workspace()
+
+    def _build_decoder(self, w):
+        cfg = self.cfg
+        B, h, wd = self.B, self.h, self.w
+        lc = cfg.latent_channels
+        boc = list(reversed(cfg.block_out_channels))
+        f = self.fwd
+        zq = self._buf((B, lc, h, wd), torch.float32)
+        wpq = self._w32(w["post_quant_conv.weight"].reshape(lc, lc))
+        bpq = self._w32(w["post_quant_conv.bias"])
+        f.append(partial(ops.conv1x1_nchw, self.z_in, wpq, bpq, zq, B, lc, lc, h * wd, 1.0 / cfg.scaling_factor))
+        M = B * h * wd
+        col = self._buf((M, 64))
+        cm = boc[0]
+        w_in = self._w16(packing.pad_rows(packing.conv3x3_fwd(w["decoder.conv_in.weight"]), 64))
+        b_in = self._w32(w["decoder.conv_in.bias"])
+        h0 = self._buf((M, cm))
+        f.append(partial(ops.im2col3x3_small, zq, col, B, lc, h, wd, h, wd, 1, 1, 1, zq.stride()))
+        f.append(partial(ops.gemm, col, w_in, h0, bias=b_in))
+        cur = T(h0, need_grad=False)
+        cur = self._resnet(cur, cm, cm, "decoder.mid_block.resnets.0.", w, None, h, wd, need_dx=False)
+        cur = self._mid_attention(cur, cm, "decoder.mid_block.attentions.0.", w, h * wd)
+        cur = self._resnet(cur, cm, cm, "decoder.mid_block.resnets.1.", w, None, h, wd, need_dx=False)
+        cin = cm
+        for i, cout in enumerate(boc):
+            for j in range(cfg.layers_per_block + 1):
+                cur = self._resnet(cur, cin if j == 0 else cout, cout, f"decoder.up_blocks.{i}.resnets.{j}.", w, None,
+                                   h, wd, need_dx=False)
+            if i < len(boc) - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv."
+                wu = self._w16(packing.conv3x3_fwd(w[p + "weight"]))
+                bu = self._w32(w[p + "bias"])
+                up = T(self._buf((4 * cur.rows, cout)), need_grad=False)
+                f.append(partial(ops.gemm, cur.v, wu, up.v, bias=bu, M=4 * cur.rows,
+                                 conv=self._conv_desc(h, wd, cout, 2 * h, 2 * wd, 1, 1, 1, cur.v.stride(0))))
+                cur = up
+                h, wd = 2 * h, 2 * wd
+            cin = cout
+        n, _ = self._gn(cur, "decoder.conv_norm_out", w, cfg.norm_eps, True)
+        co = cfg.in_channels
+        w_o = self._w16(packing.conv3x3_fwd(w["decoder.conv_out.weight"]))
+        b_o = self._w32(w["decoder.conv_out.bias"])
+        self.rgb = self._buf((B * h * wd, 8))  # 3 channels used, row stride 8
+        f.append(partial(ops.gemm, n, w_o, self.rgb[:, :co], bias=b_o, M=B * h * wd,
+                         conv=self._conv_desc(h, wd, boc[-1], h, wd, 1, 1, 0, boc[-1])))
+        f.append(partial(ops.image_postprocess, self.rgb[:, :co], self.image, B * h * wd, co))

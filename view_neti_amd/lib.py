@@ -144,6 +144,9 @@ SIGNATURES = {
     "rng_advance": [c_vp, c_vp],
     "sample_add_noise": [c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                          c_vp],
+    "cfg_sampler_step": [c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_vp],
+    "conv1x1_nchw_f32": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f, c_vp],
+    "image_postprocess": [c_vp, c_ll, c_vp, c_ll, c_int, c_vp],
     "mse_loss_grad": [c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "adamw_flat": [c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, c_vp],
     "adamw_segments": [c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp],

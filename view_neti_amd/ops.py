@@ -213,6 +213,19 @@ def sample_add_noise(moments, eps, noise, t, ac, scaling, vpred, latents, noisy,
             1 if vpred else 0, _p(latents), _p(noisy), _p(target), Bn, Lc, HW, stream())
 
 
+def cfg_sampler_step(pred, x, m_prev, x_in, Bn, Lc, HW, guidance, alpha_t, sigma_t, cx, c0, c1, v_prediction):
+    _l.call("cfg_sampler_step", _p(pred), _ld(pred), _p(x), _p(m_prev), _p(x_in), Bn, Lc, HW, guidance, alpha_t,
+            sigma_t, cx, c0, c1, 1 if v_prediction else 0, stream())
+
+
+def conv1x1_nchw(x, W, bias, out, Bn, Ci, Co, HW, in_scale=1.0):
+    _l.call("conv1x1_nchw_f32", _p(x), _p(W), _p(bias), _p(out), Bn, Ci, Co, HW, in_scale, stream())
+
+
+def image_postprocess(img, out, n_pix, channels):
+    _l.call("image_postprocess", _p(img), _ld(img), _p(out), n_pix, channels, stream())
+
+
 def mse_loss_grad(pred, target, dpred, loss_sum, loss_scale, Bn, Lc, HW):
     _l.call("mse_loss_grad", _p(pred), _ld(pred), _p(target), _p(dpred), _ld(dpred), _p(loss_sum), _p(loss_scale),
             Bn, Lc, HW, stream())

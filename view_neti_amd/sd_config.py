@@ -259,6 +259,39 @@ def vae_encoder_shapes(cfg: VAEConfig) -> Shapes:
     return s
 
 
+def vae_decoder_shapes(cfg: VAEConfig) -> Shapes:
+    """AutoencoderKL `post_quant_conv` + `decoder.*` (diffusers 0.14 key names)."""
+    s: Shapes = {}
+    boc = list(reversed(cfg.block_out_channels))
+    lc = cfg.latent_channels
+    s["post_quant_conv.weight"] = (lc, lc, 1, 1)
+    s["post_quant_conv.bias"] = (lc,)
+    cm = boc[0]
+    s["decoder.conv_in.weight"] = (cm, lc, 3, 3)
+    s["decoder.conv_in.bias"] = (cm,)
+    _resnet(s, "decoder.mid_block.resnets.0.", cm, cm, None)
+    a = "decoder.mid_block.attentions.0."
+    s[a + "group_norm.weight"] = (cm,)
+    s[a + "group_norm.bias"] = (cm,)
+    for n in ("query", "key", "value", "proj_attn"):
+        s[a + n + ".weight"] = (cm, cm)
+        s[a + n + ".bias"] = (cm,)
+    _resnet(s, "decoder.mid_block.resnets.1.", cm, cm, None)
+    cin = cm
+    for i, cout in enumerate(boc):
+        for j in range(cfg.layers_per_block + 1):
+            _resnet(s, f"decoder.up_blocks.{i}.resnets.{j}.", cin if j == 0 else cout, cout, None)
+        if i < len(boc) - 1:
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (cout,)
+        cin = cout
+    s["decoder.conv_norm_out.weight"] = (boc[-1],)
+    s["decoder.conv_norm_out.bias"] = (boc[-1],)
+    s["decoder.conv_out.weight"] = (cfg.in_channels, boc[-1], 3, 3)
+    s["decoder.conv_out.bias"] = (cfg.in_channels,)
+    return s
+
+
 def clip_text_shapes(cfg: CLIPTextConfig) -> Shapes:
     s: Shapes = {}
     d, f = cfg.hidden_size, cfg.intermediate_size

@@ -101,6 +101,10 @@ def vae_weights(cfg: sc.VAEConfig, seed: int = 1234, device="cpu"):
     return make_state_dict(sc.vae_encoder_shapes(cfg), seed + 1, device)
 
 
+def vae_decoder_weights(cfg: sc.VAEConfig, seed: int = 1234, device="cpu"):
+    return make_state_dict(sc.vae_decoder_shapes(cfg), seed + 3, device)
+
+
 def clip_weights(cfg: sc.CLIPTextConfig, seed: int = 1234, device="cpu"):
     return make_state_dict(sc.clip_text_shapes(cfg), seed + 2, device)
 
