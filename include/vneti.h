@@ -227,6 +227,14 @@ int vneti_sample_add_noise(const void* moments, long long ldm, const float* eps,
 int vneti_cfg_sampler_step(const void* pred, long long ldp, float* x, float* m_prev, float* x_in, int Bn,
                            int Lc, int HW, float guidance, float alpha_t, float sigma_t, float cx,
                            float c0, float c1, int v_prediction, void* stream);
+/* hipGraph-replayable form of the sampler step: the scalars {alpha_t, sigma_t, cx, c0, c1} are row step[0]
+ * of a device table (T x 5 floats) and the UNet/text timestep inputs are filled from a device table of the
+ * sampler's timesteps, so one captured step is replayed for every timestep; vneti_counter_advance moves on. */
+int vneti_cfg_sampler_step_table(const void* pred, long long ldp, float* x, float* m_prev, float* x_in,
+                                 int Bn, int Lc, int HW, float guidance, const float* coef_table,
+                                 const int* step, int v_prediction, void* stream);
+int vneti_table_fill_i64(void* dst_i64, int n, const void* table_i64, const int* step, void* stream);
+int vneti_counter_advance(int* counter, void* stream);
 /* AutoencoderKL.post_quant_conv on the latents scaled by 1/scaling_factor (pipeline.decode_latents):
  * NCHW f32, out[b][o][p] = bias[o] + sum_c W[o][c] x[b][c][p] * in_scale; channel counts <= 8 */
 int vneti_conv1x1_nchw_f32(const float* x, const float* W, const float* bias, float* out, int Bn, int Ci,

@@ -239,6 +239,37 @@ __global__ void cfg_sampler_step_kernel(const half_t* pred, long long ldp, float
   x_in[gid] = xn;
   x_in[(long long)total + gid] = xn;
 }
+// graph-replayable variant: the per-step scalars {alpha_t, sigma_t, cx, c0, c1} come from a device table row
+// selected by a device step counter, so ONE captured sampler step replays for every timestep
+__global__ void cfg_sampler_step_table_kernel(const half_t* pred, long long ldp, float* x, float* m_prev, float* x_in,
+                                              int Bn, int Lc, int HW, float guidance, const float* coef_table,
+                                              const int* step, int vpred) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = Bn * Lc * HW;
+  if (gid >= total) return;
+  const float* cf = coef_table + 5 * step[0];
+  const float alpha_t = cf[0], sigma_t = cf[1], cx = cf[2], c0 = cf[3], c1 = cf[4];
+  int p = gid % HW;
+  int c = (gid / HW) % Lc;
+  int b = gid / (HW * Lc);
+  float u = (float)pred[((long long)b * HW + p) * ldp + c];
+  float cnd = (float)pred[((long long)(Bn + b) * HW + p) * ldp + c];
+  float e = u + guidance * (cnd - u);
+  float xv = x[gid];
+  float x0 = vpred ? (alpha_t * xv - sigma_t * e) : (xv - sigma_t * e) / alpha_t;
+  float xn = cx * xv + c0 * x0 + c1 * m_prev[gid];
+  x[gid] = xn;
+  m_prev[gid] = x0;
+  x_in[gid] = xn;
+  x_in[(long long)total + gid] = xn;
+}
+__global__ void table_fill_i64_kernel(long long* dst, int n, const long long* table, const int* step) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n) dst[gid] = table[step[0]];
+}
+__global__ void counter_advance_kernel(int* c) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += 1;
+}
 // tiny 1x1 conv on NCHW f32 latents (AutoencoderKL.post_quant_conv after the 1/scaling_factor of
 // pipeline.decode_latents): out[b][o][p] = bias[o] + sum_c W[o][c] * x[b][c][p] * in_scale,  C <= 8
 __global__ void conv1x1_nchw_kernel(const float* x, const float* W, const float* bias, float* out, int Bn, int Ci,
@@ -499,6 +530,30 @@ extern "C" int vneti_cfg_sampler_step(const void* pred, long long ldp, float* x,
   hipLaunchKernelGGL(cfg_sampler_step_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const half_t*)pred, ldp, x,
                      m_prev, x_in, Bn, Lc, HW, guidance, alpha_t, sigma_t, cx, c0, c1, v_prediction);
   return vneti_check_launch("cfg_sampler_step");
+}
+
+extern "C" int vneti_cfg_sampler_step_table(const void* pred, long long ldp, float* x, float* m_prev, float* x_in,
+                                            int Bn, int Lc, int HW, float guidance, const float* coef_table,
+                                            const int* step, int v_prediction, void* stream) {
+  VN_REQUIRE(pred && x && m_prev && x_in && coef_table && step && Bn > 0 && Lc > 0 && HW > 0,
+             "cfg_sampler_step_table: bad arguments");
+  int n = Bn * Lc * HW;
+  hipLaunchKernelGGL(cfg_sampler_step_table_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const half_t*)pred, ldp, x,
+                     m_prev, x_in, Bn, Lc, HW, guidance, coef_table, step, v_prediction);
+  return vneti_check_launch("cfg_sampler_step_table");
+}
+
+extern "C" int vneti_table_fill_i64(void* dst, int n, const void* table, const int* step, void* stream) {
+  VN_REQUIRE(dst && table && step && n > 0, "table_fill_i64: bad arguments");
+  hipLaunchKernelGGL(table_fill_i64_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (long long*)dst, n,
+                     (const long long*)table, step);
+  return vneti_check_launch("table_fill_i64");
+}
+
+extern "C" int vneti_counter_advance(int* counter, void* stream) {
+  VN_REQUIRE(counter, "counter_advance: null pointer");
+  hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(64), 0, ST, counter);
+  return vneti_check_launch("counter_advance");
 }
 
 extern "C" int vneti_conv1x1_nchw_f32(const float* x, const float* W, const float* bias, float* out, int Bn, int Ci,

@@ -102,6 +102,12 @@ class InferenceEngine:
         self.x = torch.zeros(shape, dtype=torch.float32, device=device)
         self.m_prev = torch.zeros_like(self.x)
         self.image = self.decoder.image
+        self.step_idx = torch.zeros(1, dtype=torch.int32, device=device)
+        # device tables a captured sampler step reads (row = step_idx): {alpha_t, sigma_t, cx, c0, c1}, timestep
+        self.coef_table = torch.zeros((cfg.ddpm.num_train_timesteps, 5), dtype=torch.float32, device=device)
+        self.ts_table = torch.zeros((cfg.ddpm.num_train_timesteps,), dtype=torch.int64, device=device)
+        self._graph = None
+        self._graph_key = None
 
     # ------------------------------------------------------------------ conditioning
     def set_negative_prompt(self, input_ids: torch.Tensor):
@@ -127,7 +133,7 @@ class InferenceEngine:
     # ------------------------------------------------------------------ the loop
     @torch.no_grad()
     def generate(self, latents: torch.Tensor, num_inference_steps: int = 50, guidance_scale: float = 7.5,
-                 kind: str = "dpm++2m", decode: bool = True):
+                 kind: str = "dpm++2m", decode: bool = True, use_graph: bool = True):
         """latents: (B, 4, h, w) N(0,1) draw (`prepare_latents`, init_noise_sigma = 1 for both samplers).
         Returns the images f32 [B, H, W, 3] in [0,1] (the array `numpy_to_pil` receives) or the final latents."""
         if guidance_scale <= 1.0:
@@ -139,21 +145,65 @@ class InferenceEngine:
         self.unet.x_in[:B].copy_(self.x)
         self.unet.x_in[B:].copy_(self.x)
         vpred = self.cfg.ddpm.prediction_type == "v_prediction"
-        for i, t in enumerate(ts):
-            self.t_text.fill_(t)
-            self.unet.timesteps.fill_(t)
-            self.text.forward()
-            self.unet.ctx_k[:, B * L:].copy_(self.ctx_k)
-            self.unet.ctx_v[:, B * L:].copy_(self.ctx_v)
-            self.unet.forward()
-            cx, c0, c1, a_t, s_t = step_coefficients(kind, self.ac, ts, i)
-            ops.cfg_sampler_step(self.unet.pred, self.x, self.m_prev, self.unet.x_in, B, self.Lc, self.h * self.w,
-                                 guidance_scale, a_t, s_t, cx, c0, c1, vpred)
+        if use_graph:
+            # one captured sampler step, replayed T times: timesteps and step scalars come from device tables
+            rows = [step_coefficients(kind, self.ac, ts, i) for i in range(len(ts))]
+            self.coef_table[: len(ts)].copy_(torch.tensor([[a, s_, cx, c0, c1] for (cx, c0, c1, a, s_) in rows],
+                                                          dtype=torch.float32))
+            self.ts_table[: len(ts)].copy_(torch.tensor(ts, dtype=torch.int64))
+            self.step_idx.zero_()
+            key = (guidance_scale, vpred)
+            if self._graph is None or self._graph_key != key:
+                self._capture(guidance_scale, vpred)
+                self._graph_key = key
+                self.step_idx.zero_()
+                self.x.copy_(latents)
+                self.m_prev.zero_()
+                self.unet.x_in[:B].copy_(self.x)
+                self.unet.x_in[B:].copy_(self.x)
+            for _ in ts:
+                self._graph.replay()
+        else:
+            for i, t in enumerate(ts):
+                self.t_text.fill_(t)
+                self.unet.timesteps.fill_(t)
+                self.text.forward()
+                self.unet.ctx_k[:, B * L:].copy_(self.ctx_k)
+                self.unet.ctx_v[:, B * L:].copy_(self.ctx_v)
+                self.unet.forward()
+                cx, c0, c1, a_t, s_t = step_coefficients(kind, self.ac, ts, i)
+                ops.cfg_sampler_step(self.unet.pred, self.x, self.m_prev, self.unet.x_in, B, self.Lc,
+                                     self.h * self.w, guidance_scale, a_t, s_t, cx, c0, c1, vpred)
         if not decode:
             return self.x
         self.decoder.z_in.copy_(self.x)
         self.decoder.forward()
         return self.image
+
+    def _one_step(self, guidance_scale, vpred):
+        B, L = self.B, self.L
+        ops.table_fill_i64(self.t_text, self.ts_table, self.step_idx)
+        ops.table_fill_i64(self.unet.timesteps, self.ts_table, self.step_idx)
+        self.text.forward()
+        self.unet.ctx_k[:, B * L:].copy_(self.ctx_k)
+        self.unet.ctx_v[:, B * L:].copy_(self.ctx_v)
+        self.unet.forward()
+        ops.cfg_sampler_step_table(self.unet.pred, self.x, self.m_prev, self.unet.x_in, B, self.Lc, self.h * self.w,
+                                   guidance_scale, self.coef_table, self.step_idx, vpred)
+        ops.counter_advance(self.step_idx)
+
+    def _capture(self, guidance_scale, vpred):
+        """capture one sampler step (the warm-up run below is a real step: the caller re-seeds x afterwards)."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._one_step(guidance_scale, vpred)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, stream=s):
+                self._one_step(guidance_scale, vpred)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
 
     def memory_bytes(self) -> int:
         return self.unet.bytes + self.text.bytes + self.decoder.bytes

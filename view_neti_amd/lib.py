@@ -145,6 +145,9 @@ SIGNATURES = {
     "sample_add_noise": [c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                          c_vp],
     "cfg_sampler_step": [c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_vp],
+    "cfg_sampler_step_table": [c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_vp, c_vp, c_int, c_vp],
+    "table_fill_i64": [c_vp, c_int, c_vp, c_vp, c_vp],
+    "counter_advance": [c_vp, c_vp],
     "conv1x1_nchw_f32": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f, c_vp],
     "image_postprocess": [c_vp, c_ll, c_vp, c_ll, c_int, c_vp],
     "mse_loss_grad": [c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_int, c_int, c_int, c_vp],

@@ -218,6 +218,19 @@ def cfg_sampler_step(pred, x, m_prev, x_in, Bn, Lc, HW, guidance, alpha_t, sigma
             sigma_t, cx, c0, c1, 1 if v_prediction else 0, stream())
 
 
+def cfg_sampler_step_table(pred, x, m_prev, x_in, Bn, Lc, HW, guidance, coef_table, step, v_prediction):
+    _l.call("cfg_sampler_step_table", _p(pred), _ld(pred), _p(x), _p(m_prev), _p(x_in), Bn, Lc, HW, guidance,
+            _p(coef_table), _p(step), 1 if v_prediction else 0, stream())
+
+
+def table_fill_i64(dst, table, step):
+    _l.call("table_fill_i64", _p(dst), dst.numel(), _p(table), _p(step), stream())
+
+
+def counter_advance(counter):
+    _l.call("counter_advance", _p(counter), stream())
+
+
 def conv1x1_nchw(x, W, bias, out, Bn, Ci, Co, HW, in_scale=1.0):
     _l.call("conv1x1_nchw_f32", _p(x), _p(W), _p(bias), _p(out), Bn, Ci, Co, HW, in_scale, stream())
 
