@@ -50,3 +50,20 @@ def load_sd_weights(cfg: sc.SDConfig, path: str, device: str = "cuda") -> Tuple[
                 f32(clip, sc.clip_text_shapes(cfg.clip)), False)
     return (synth.unet_weights(cfg.unet, device=device), synth.vae_weights(cfg.vae, device=device),
             synth.clip_weights(cfg.clip, device=device), True)
+
+
+def load_vae_decoder_weights(cfg: sc.SDConfig, path: str, device: str = "cuda") -> Tuple[Dict, bool]:
+    """`post_quant_conv.*` + `decoder.*` of the same checkpoint directory (inference path); synthetic otherwise."""
+    need = sc.vae_decoder_shapes(cfg.vae)
+    if path and os.path.isdir(os.path.join(str(path), "vae")):
+        raw = _read_dir(os.path.join(path, "vae"))
+        vae = {}
+        for k, v in raw.items():
+            for new, old in _VAE_RENAME.items():
+                k = k.replace(f"attentions.0.{new}.", f"attentions.0.{old}.")
+            vae[k] = v
+        missing = [k for k in need if k not in vae]
+        if missing:
+            raise KeyError(f"vae decoder: {len(missing)} tensors missing from checkpoint, e.g. {missing[:3]}")
+        return {k: vae[k].float().reshape(need[k]) for k in need}, False
+    return synth.vae_decoder_weights(cfg.vae, device=device), True
