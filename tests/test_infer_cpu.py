@@ -1,0 +1,100 @@
+"""Host logic of the inference path (no GPU): sampler schedules and step algebra against a literal transcription of
+the update rules of diffusers 0.14's DPMSolverMultistepScheduler / DDIMScheduler, and the PromptManager contract."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd_ref as R
+from view_neti_amd import sd_config as sc
+from view_neti_amd.compat.prompt_manager import PromptManager
+from view_neti_amd.compat.tokenizer import HashTokenizer
+from view_neti_amd.engine.infer import inference_timesteps, step_coefficients
+
+
+def test_timestep_schedules():
+    assert inference_timesteps("dpm++2m", 10) == [999, 899, 799, 699, 599, 500, 400, 300, 200, 100]
+    assert inference_timesteps("ddim", 50)[:3] == [981, 961, 941] and inference_timesteps("ddim", 50)[-1] == 1
+    assert inference_timesteps("dpm++2m", 30) == R.inference_timesteps("dpm++2m", 30)
+    with pytest.raises(ValueError):
+        inference_timesteps("euler", 10)
+
+
+def _dpm_literal(ac, ts, x, outs):
+    """DPMSolverMultistepScheduler.step for algorithm_type='dpmsolver++', solver_order=2, solver_type='midpoint',
+    lower_order_final=True, written the way the scheduler writes it (on data predictions `outs[i]`)."""
+    al, sg = ac.sqrt(), (1 - ac).sqrt()
+    lam = al.log() - sg.log()
+    n = len(ts)
+    hist, lower = [], 0
+    for i, t in enumerate(ts):
+        prev_t = 0 if i == n - 1 else ts[i + 1]
+        hist.append(outs[i])
+        lower_final = (i == n - 1) and n < 15
+        if lower < 1 or lower_final:
+            h = lam[prev_t] - lam[t]
+            x = (sg[prev_t] / sg[t]) * x - (al[prev_t] * (torch.exp(-h) - 1.0)) * hist[-1]
+        else:
+            s0, s1 = t, ts[i - 1]
+            m0, m1 = hist[-1], hist[-2]
+            h, h_0 = lam[prev_t] - lam[s0], lam[s0] - lam[s1]
+            r0 = h_0 / h
+            D0, D1 = m0, (1.0 / r0) * (m0 - m1)
+            x = (sg[prev_t] / sg[s0]) * x - (al[prev_t] * (torch.exp(-h) - 1.0)) * D0 \
+                - 0.5 * (al[prev_t] * (torch.exp(-h) - 1.0)) * D1
+        if lower < 2:
+            lower += 1
+    return x
+
+
+def _ddim_literal(ac, ts, x, eps_list, n_train=1000):
+    """DDIMScheduler.step, eta=0, epsilon prediction, set_alpha_to_one=False."""
+    for i, t in enumerate(ts):
+        prev_t = t - n_train // len(ts)
+        a_t = ac[t]
+        a_p = ac[prev_t] if prev_t >= 0 else ac[0]
+        e = eps_list[i]
+        x0 = (x - (1 - a_t).sqrt() * e) / a_t.sqrt()
+        x = a_p.sqrt() * x0 + (1 - a_p).sqrt() * e
+    return x
+
+
+@pytest.mark.parametrize("kind,steps", [("dpm++2m", 10), ("dpm++2m", 25), ("ddim", 20)])
+def test_step_coefficients_reproduce_the_schedulers(kind, steps):
+    ac = R.alphas_cumprod(sc.sd15().ddpm).double()
+    ts = inference_timesteps(kind, steps)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(7, generator=g, dtype=torch.float64)
+    model_out = [torch.randn(7, generator=g, dtype=torch.float64) for _ in ts]  # epsilon predictions
+    # linear form used on the GPU: x <- cx x + c0 x0 + c1 x0_prev, x0 = (x - sigma e)/alpha
+    xl, prev = x.clone(), torch.zeros_like(x)
+    x0s = []
+    for i in range(steps):
+        cx, c0, c1, a_t, s_t = step_coefficients(kind, ac, ts, i)
+        x0 = (xl - s_t * model_out[i]) / a_t
+        x0s.append(x0)
+        xl, prev = cx * xl + c0 * x0 + c1 * prev, x0
+    if kind == "ddim":
+        want = _ddim_literal(ac, ts, x.clone(), model_out)
+    else:
+        want = _dpm_literal(ac, ts, x.clone(), x0s)  # same data predictions, scheduler's own update rule
+    assert torch.allclose(xl, want, rtol=1e-9, atol=1e-9), (xl - want).abs().max()
+
+
+def test_prompt_manager_contract():
+    tk = HashTokenizer()
+    tk.add_tokens(["<view_a>", "<view_b>", "<toy>"])
+    ids = {t: tk.convert_tokens_to_ids(t) for t in ("<view_a>", "<view_b>", "<toy>")}
+    pm = PromptManager(tk, placeholder_view_token_ids=[ids["<view_a>"], ids["<view_b>"]],
+                       placeholder_object_token_ids=[ids["<toy>"]],
+                       view_params_fn=lambda i: torch.full((12,), float(i)))
+    e = pm.embed_prompt("<view_b>. A photo of a <toy>", truncation_idx=16, num_images_per_prompt=2)
+    assert e.input_ids.shape == (1, 77) and int(e.input_ids_placeholder_object) == ids["<toy>"]
+    assert int(e.input_ids_placeholder_view) == ids["<view_b>"] and e.view_params.shape == (1, 12)
+    assert float(e.view_params[0, 0]) == ids["<view_b>"] and e.truncation_idx == 16 and e.num_images_per_prompt == 2
+    plain = pm.embed_prompt("A photo of a cat")
+    assert int(plain.input_ids_placeholder_object) == -1 and int(plain.input_ids_placeholder_view) == -1
+    assert plain.view_params is None
+    with pytest.raises(AssertionError):
+        pm.embed_prompt("<view_a> <view_b> a <toy>")  # two tokens of one kind (prompt_manager.py:62-64)
