@@ -35,7 +35,7 @@ import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0  # fp16/bf16 dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3: "gemm_kernel<64,64,32,32>",
-              4: "gemm_kernel<256,128,64,64>", 5: "gemm_kernel<256,256,64,64>"}
+              4: "gemm_kernel<256,128,64,64>", 5: "gemm_kernel<256,256,64,64>", 6: "gemm_kernel<256,128,64,64,ring3>"}
 # algorithmic FLOPs per sample at 512^2, SD-1.5: VAE 1116.7 + CLIP 16x13.3 + UNet fwd 803.3
 # + UNet dgrad 929.4 + CLIP dgrad 216 GF
 ALGO_GFLOP_PER_SAMPLE_512 = 3278.0
@@ -118,7 +118,7 @@ def pmc_traffic(tile_name: str):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.json")))
     if not files:
         return {"traffic": None}
-    dims = re.findall(r"\d+", tile_name)
+    dims = re.findall(r"\d+", tile_name.split(",ring")[0])
     pats = ["gemm_kernel<" + ", ".join(dims) + ", false", "gemm_kernelILi" + "ELi".join(dims) + "ELb0E"]
     try:
         ks = json.load(open(files[-1]))["kernels"]

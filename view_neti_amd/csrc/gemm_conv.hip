@@ -79,8 +79,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA>
+template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs g) {
+  static_assert(NSTG == 2 || (NSTG == 3 && DMA), "the 3-stage ring is LDS-DMA only");
   constexpr int NWM = BM / WM, NWN = BN / WN;
   constexpr int NT = NWM * NWN * 64;
   constexpr int RSTEP = NT / 8;  // tile rows covered by one pass of all threads
@@ -89,7 +90,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int CS_LD = F32OUT ? (BN + 4) : (BN + 8);  // elements
   constexpr int CS_BYTES = BM * CS_LD * (F32OUT ? 4 : 2);
-  constexpr int LDS_BYTES = (2 * STAGE_BYTES > CS_BYTES) ? 2 * STAGE_BYTES : CS_BYTES;
+  constexpr int LDS_BYTES = (NSTG * STAGE_BYTES > CS_BYTES) ? NSTG * STAGE_BYTES : CS_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
   const int tid = threadIdx.x;
@@ -265,52 +266,87 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   const int kt_begin = kz * g.kt_per_split;
   const int kt_end = min(nk_total, kt_begin + g.kt_per_split);
 
-  issue(kt_begin, 0, true);
-  store_lds(0);
-  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1, false);
-    const char* As = smem + cur * STAGE_BYTES;
+  half8 af[2][MI], bf[2][NI];
+  auto load_frags = [&](int buf, int stage, int ks) {
+    const char* As = smem + stage * STAGE_BYTES;
     const char* Bs = As + BM * 128;
-    // fragments double-buffered in registers: the ds_reads of k-step s+1 are in flight under the
-    // MFMAs of k-step s; on the 4-wave tiles the MFMA groups run at raised priority so the partner
-    // wave's loads/address math do not steal issue slots (+10..23 % in tools/lab).
-    half8 af[2][MI], bf[2][NI];
-    auto load_frags = [&](int buf, int ks) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[buf][i] = as_half8(*reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, ks * 2 + fhalf)));
+    for (int i = 0; i < MI; ++i)
+      af[buf][i] = as_half8(*reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, ks * 2 + fhalf)));
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      bf[buf][j] = as_half8(*reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, ks * 2 + fhalf)));
+  };
+  auto mma = [&](int buf) {
+    if constexpr (NT == 256) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        bf[buf][j] = as_half8(*reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, ks * 2 + fhalf)));
-    };
-    auto mma = [&](int buf) {
-      if constexpr (NT == 256) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          // operands swapped: D[row = n][col = m]  => each lane owns 4 consecutive n of one m
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
-      if constexpr (NT == 256) __builtin_amdgcn_s_setprio(0);
-    };
-    load_frags(0, 0);
-    load_frags(1, 1);
-    mma(0);
-    load_frags(0, 2);
-    mma(1);
-    load_frags(1, 3);
-    mma(0);
-    mma(1);
-    if (kt + 1 < kt_end) store_lds(cur ^ 1);
+        // operands swapped: D[row = n][col = m]  => each lane owns 4 consecutive n of one m
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
+    if constexpr (NT == 256) __builtin_amdgcn_s_setprio(0);
+  };
+
+  if constexpr (NSTG == 3) {
+    // 3-stage ring with cross-barrier fragment prefetch: the barrier that publishes stage s+1 sits before the
+    // LAST MFMA group of step s, so the first fragments of step s+1 are fetched under it and the step boundary
+    // has no LDS-latency bubble (tools/lab: +5..24 % on this tile); DMA runs two stages ahead.
+    constexpr int PER = A_IT + B_IT;
+    issue(kt_begin, 0, true);
+    if (kt_begin + 1 < kt_end) {
+      issue(kt_begin + 1, 1, false);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, 0);
+    int st = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int st_next = st == 2 ? 0 : st + 1;
+      const int st_new = st_next == 2 ? 0 : st_next + 1;
+      if (kt + 2 < kt_end) issue(kt + 2, st_new, false);
+      load_frags(1, st, 1);
+      mma(0);
+      load_frags(0, st, 2);
+      mma(1);
+      load_frags(1, st, 3);
+      mma(0);
+      if (kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < kt_end) load_frags(0, st_next, 0);
+      mma(1);
+      st = st_next;
+    }
+    __syncthreads();  // (cheap) the epilogue reuses the ring as its C tile
+  } else {
+    issue(kt_begin, 0, true);
+    store_lds(0);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int cur = (kt - kt_begin) & 1;
+      if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1, false);
+      // fragments double-buffered in registers: the ds_reads of k-step s+1 are in flight under the
+      // MFMAs of k-step s; on the 4-wave tiles the MFMA groups run at raised priority so the partner
+      // wave's loads/address math do not steal issue slots (+10..23 % in tools/lab).
+      load_frags(0, cur, 0);
+      load_frags(1, cur, 1);
+      mma(0);
+      load_frags(0, cur, 2);
+      mma(1);
+      load_frags(1, cur, 3);
+      mma(0);
+      mma(1);
+      if (kt + 1 < kt_end) store_lds(cur ^ 1);
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   // ---- split-K: raw f32 partials straight to the workspace ---------------------------------
@@ -484,6 +520,24 @@ int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   return vneti_check_launch("gemm_kernel");
 }
 
+// 3-stage ring variant (LDS-DMA only)
+template <int BM, int BN, int WM, int WN>
+int launch_cfg_ring(GemmArgs& g, bool f32out, hipStream_t st) {
+  g.tiles_m = cdiv(g.M, BM);
+  g.tiles_n = cdiv(g.N, BN);
+  dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
+  dim3 block((BM / WM) * (BN / WN) * 64);
+  if (f32out)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3>), grid, block, 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3>), grid, block, 0, st, g);
+  if (g.ksplit > 1) {
+    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
+  }
+  return vneti_check_launch("gemm_kernel");
+}
+
 template <int BM, int BN, int WM, int WN, bool DMA>
 int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
@@ -500,7 +554,7 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
 struct TileDims {
   int bm, bn;
 };
-constexpr TileDims kTiles[6] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 256}};
+constexpr TileDims kTiles[7] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 256}, {256, 128}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -607,8 +661,9 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     cfg -= 100;
   }
   if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
-  VN_REQUIRE(cfg >= 1 && cfg <= 5, "gemm: unknown tile_hint %d", d->tile_hint);
+  VN_REQUIRE(cfg >= 1 && cfg <= 6, "gemm: unknown tile_hint %d", d->tile_hint);
   if (cfg == 5 && f32) cfg = 4;  // the 256x256 tile's f32 epilogue staging would not fit in LDS
+  if (cfg == 6 && !dma) cfg = 4;  // the 3-stage ring exists with LDS-DMA only
   long long ws_floats = d->workspace ? d->workspace_bytes / 4 : 0;
   int ks = d->split_k;
   if (ks == 0) ks = select_ksplit(d->M, d->N, d->K, batch, cfg, ws_floats);
@@ -632,6 +687,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     case 2: LAUNCH(128, 64, 64, 32);
     case 3: LAUNCH(64, 64, 32, 32);
     case 4: LAUNCH(256, 128, 64, 64);
+    case 6: return launch_cfg_ring<256, 128, 64, 64>(g, f32, st);
     default:
       return dma ? launch_cfg_f16<256, 256, 64, 64, true>(g, st) : launch_cfg_f16<256, 256, 64, 64, false>(g, st);
   }
