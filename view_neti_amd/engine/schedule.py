@@ -127,7 +127,7 @@ class Schedule:
         ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
         return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32)
 
-    def autotune(self, candidates=(1, 2, 3, 4, 5, 6), reps=4):
+    def autotune(self, candidates=(1, 2, 3, 4, 5, 6), reps=8):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
         tile configuration, with the split-K heuristic and with split-K forced off (the f32 partials
         and the reduce launch are not always worth the extra blocks), and pin the fastest pair.
@@ -146,6 +146,7 @@ class Schedule:
                         for sk in (0, 1):  # 0 = library heuristic, 1 = no split
                             kw = dict(f.keywords)
                             kw["tile_hint"], kw["split_k"] = h, sk
+                            ops.gemm(*f.args, **kw)
                             ops.gemm(*f.args, **kw)
                             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             s.record()
