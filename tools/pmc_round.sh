@@ -12,3 +12,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "$c rc=$?"; tail -1 $OUT/${TAG}_pmc_$c.log
 done
 python $REPO/tools/pmc_summary.py $TAG
+find $OUT -name "*kernel_trace.csv" -path "*_pmc_*" -delete

@@ -3,9 +3,8 @@
 #   tools/profile_round.sh r01c
 # 1. bench.py default run (JSON line)                      -> gpurun_out/<tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats of the same command  -> gpurun_out/<tag>_stats/
-# 3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only, eager launches)
-#                                                          -> gpurun_out/<tag>_pmc_{fetch,write}/
-# 4. tools/pmc_summary.py folds 2+3 into small CSV/JSON files to be copied into profiles/.
+# 3. tools/pmc_summary.py folds 2 (and the counter passes of tools/pmc_round.sh, if present) into small
+#    CSV/JSON files to be copied into profiles/.
 set -u
 TAG=${1:-r01x}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -16,8 +15,7 @@ python $REPO/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json; echo
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- \
   python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 1200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- \
-    python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > /dev/null 2> $OUT/${TAG}_pmc_$c.err
-done
+# (the counter passes live in tools/pmc_round.sh: rocprofv3 + TCC counters segfaults around the whole bench process)
 python $REPO/tools/pmc_summary.py $TAG
+# the raw per-dispatch trace is tens of MB: keep only the summaries (gpurun copies back <= 64 MiB)
+find $OUT/${TAG}_stats -name "*kernel_trace.csv" -delete
