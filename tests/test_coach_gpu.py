@@ -23,7 +23,8 @@ def test_coach_mode0_trains_and_saves(tmp_path):
         "--model.arch_view_disable_tl", "False", "--model.arch_mlp_hidden_dims", "64", "--model.use_nested_dropout",
         "False", "--optim.max_train_steps", "4", "--optim.train_batch_size", "2",
         "--optim.gradient_accumulation_steps", "2", "--optim.mixed_precision", "fp16", "--log.save_steps", "2",
-        "--log.exp_dir", str(tmp_path / "out"), "--log.exp_name", "run"])
+        "--eval.validation_steps", "2", "--eval.num_denoising_steps", "2", "--eval.num_validation_images", "2",
+        "--eval.validation_seeds", "[0, 1]", "--log.exp_dir", str(tmp_path / "out"), "--log.exp_name", "run"])
     cfg.log.exp_dir = cfg.log.exp_dir / cfg.log.exp_name
     cfg.log.logging_dir = cfg.log.exp_dir / cfg.log.logging_dir
     torch.manual_seed(cfg.seed)
@@ -36,6 +37,13 @@ def test_coach_mode0_trains_and_saves(tmp_path):
                  "mapper-final_object.pt"):
         assert (out / name).exists(), name
     assert coach.engine.opt_step.item() == 4 and not torch.equal(p0, coach.engine.params)
+    # validation grids at steps 2 and 4 (validate.py:296-309): 4 prompt templates x 2 seeds, generated with the live
+    # mapper parameters (the validator's engine aliases the trainer's bucket)
+    assert coach.validator.engine.text.mo.params.data_ptr() == coach.engine.params.data_ptr()
+    for st in (2, 4):
+        for i in range(4):
+            g = Image.open(out / f"validation-iter_{st}-denoisesteps_2_upsample_1_imgs_t2i_{i}.png")
+            assert g.size == (2 * 64, 64)
     # lr rule of coach.py:728-733: 1e-3 * accum(2) * bs(2) * world(1)
     assert abs(float(coach.engine.hyper[0]) - 4e-3) < 1e-9
     tok_id = coach.placeholder_object_token_ids[0]
@@ -152,7 +160,9 @@ def test_train_then_generate(tmp_path, monkeypatch):
         "--model.arch_view_net", "15", "--model.arch_view_disable_tl", "False", "--model.arch_mlp_hidden_dims", "64",
         "--model.use_nested_dropout", "False", "--model.pe_sigma_exp_key", "2", "--optim.max_train_steps", "3",
         "--optim.train_batch_size", "1", "--optim.gradient_accumulation_steps", "1", "--optim.mixed_precision", "fp16",
-        "--log.save_steps", "100", "--log.exp_dir", str(tmp_path / "out"), "--log.exp_name", "m2"])
+        "--log.save_steps", "100", "--eval.validation_steps", "3", "--eval.num_denoising_steps", "2",
+        "--eval.num_validation_images", "1", "--eval.validation_seeds", "[0]", "--log.exp_dir", str(tmp_path / "out"),
+        "--log.exp_name", "m2"])
     cfg.log.exp_dir = cfg.log.exp_dir / cfg.log.exp_name
     cfg.log.logging_dir = cfg.log.exp_dir / cfg.log.logging_dir
     torch.manual_seed(cfg.seed)
@@ -160,6 +170,12 @@ def test_train_then_generate(tmp_path, monkeypatch):
     coach.train()
     eng = coach.engine
     view_tok = coach.train_dataset.placeholder_view_tokens[0]
+    # view-mode validation: camidx -> [image per seed] for the 3 training views + one grid per seed
+    val = torch.load(cfg.log.exp_dir / "validation-iter_3-denoisesteps_2_numseeds_1_upsample_1.pt", weights_only=False)
+    assert sorted(val) == sorted(coach.train_dataset.lookup_view_token_to_camidx[t]
+                                 for t in coach.train_dataset.placeholder_view_tokens)
+    assert all(len(v) == 1 and v[0].shape == (384, 512, 3) and v[0].dtype == np.uint8 for v in val.values())
+    assert Image.open(cfg.log.exp_dir / "validation-iter_3-denoisesteps_2_numseeds_1_upsample_1_seed_0.png").size == (3 * 512, 384)
     pipe, pm = load_inference(cfg.log.exp_dir, "mapper-final", batch=1)
     ie = pipe.engine
     assert (ie.h, ie.w) == (48, 64)  # dtu_preprocess_key 1 -> 384 x 512

@@ -12,8 +12,9 @@ What is mirrored (file:line of the reference):
   * nested dropout / unconstrained bypass flags forwarded to the mappers   coach.py:525-584
   * lr = lr * accum * batch * world when scale_lr                         coach.py:727-733
   * train loop, save every log.save_steps + final, file names            coach.py:137-274
-What differs on purpose: DESIGN.md §5 (no embedding restore, device RNG, flat-bucket all-reduce);
-validation/inference (`eval.*`) is out of scope for this round.
+  * validation images every eval.validation_steps (compat/validate.py: the live mappers on the inference engine;
+    the DTU metric harness itself stays out of scope)                     coach.py:243-251, validate.py
+What differs on purpose: DESIGN.md §5 (no embedding restore, device RNG, flat-bucket all-reduce).
 """
 from __future__ import annotations
 
@@ -91,6 +92,13 @@ class Coach:
             grad_accum=cfg.optim.gradient_accumulation_steps, hidden_object=first.hidden,
             unconstrained_object=m.bypass_unconstrained_object, unconstrained_view=m.bypass_unconstrained_view,
             nested_dropout_prob=m.nested_dropout_prob if m.use_nested_dropout else 0.0, **kw)
+        self.validator = None
+        if cfg.eval.validation_prompts is not None and cfg.eval.validation_steps <= cfg.optim.max_train_steps \
+                and self.rank == 0:
+            from .sd_weights import load_vae_decoder_weights
+            from .validate import ValidationHandler
+            dec_w, _ = load_vae_decoder_weights(self.sd, str(cfg.model.pretrained_model_name_or_path), device)
+            self.validator = ValidationHandler(self, unet_w, dec_w, clip_w)
         del unet_w, vae_w, clip_w
         self.checkpoint_handler = CheckpointHandler(
             cfg, self.train_dataset.placeholder_view_tokens, self.placeholder_view_token_ids,
@@ -268,6 +276,8 @@ class Coach:
                                  f"{global_step / (time.time() - t0):.2f} it/s")
                     if global_step % cfg.log.save_steps == 0:
                         self.save(f"learned_embeds-steps-{global_step}.bin", f"mapper-steps-{global_step}.pt")
+                    if self.validator is not None and global_step % cfg.eval.validation_steps == 0:  # coach.py:243,834
+                        self.validator.infer(global_step)
                 if global_step >= cfg.optim.max_train_steps:
                     break
         torch.cuda.synchronize()

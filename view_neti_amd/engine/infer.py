@@ -72,7 +72,11 @@ class InferenceEngine:
                  mapper_view: Optional[Dict[str, torch.Tensor]] = None, w_enc_view: Optional[torch.Tensor] = None,
                  norm_scale_view: Optional[float] = None, alpha_view: float = 0.2, n_view_params: int = 12,
                  unconstrained_object: bool = False, unconstrained_view: bool = False, hidden_object: int = 64,
-                 device: str = "cuda"):
+                 device: str = "cuda", params_object: Optional[torch.Tensor] = None,
+                 params_view: Optional[torch.Tensor] = None, object_slot: Optional[torch.Tensor] = None,
+                 object_slot_stride: int = 0):
+        """params_object / params_view: flat device buckets to ALIAS instead of copying the state dicts (validation
+        during training reads the live parameters); object_slot (+stride) picks one mapper of a multi-object bucket."""
         self.cfg = cfg
         self.B = batch
         self.dev = device
@@ -88,12 +92,15 @@ class InferenceEngine:
         self.t_text = torch.zeros(B, dtype=torch.int64, device=device)
         self.ctx_k = torch.zeros((nl, B * L, D), dtype=torch.float16, device=device)
         self.ctx_v = torch.zeros_like(self.ctx_k)
-        mo = MapperState(flatten_mapper_state(mapper_object).to(device), w_enc_object.to(device).float().contiguous(),
-                         norm_scale_object, alpha_object, hidden=hidden_object, unconstrained=unconstrained_object)
+        po = params_object if params_object is not None else flatten_mapper_state(mapper_object).to(device)
+        mo = MapperState(po, w_enc_object.to(device).float().contiguous(), norm_scale_object, alpha_object,
+                         hidden=hidden_object, unconstrained=unconstrained_object, slot=object_slot,
+                         slot_stride=object_slot_stride)
         mv = None
-        if mapper_view is not None:
-            mv = MapperState(flatten_mapper_state(mapper_view).to(device), w_enc_view.to(device).float().contiguous(),
-                             norm_scale_view, alpha_view, unconstrained=unconstrained_view)
+        if mapper_view is not None or params_view is not None:
+            pv = params_view if params_view is not None else flatten_mapper_state(mapper_view).to(device)
+            mv = MapperState(pv, w_enc_view.to(device).float().contiguous(), norm_scale_view, alpha_view,
+                             unconstrained=unconstrained_view)
         self.text = TextEngine(cfg.clip, clip_w, nl, batch, self.t_text, self.ctx_k, self.ctx_v, None, None, mo, None,
                                mv, None, n_view_params, False, device, need_backward=False)
         self.text.training = False
