@@ -196,7 +196,7 @@ def test_im2col_small_and_conv_in():
 
 
 # ------------------------------------------------------------------------------------------ norms
-@pytest.mark.parametrize("Cc,HW", [(320, 256), (128, 1024), (2560, 64), (960, 100)])
+@pytest.mark.parametrize("Cc,HW", [(320, 256), (128, 1024), (2560, 64), (960, 100), (320, 4096), (128, 40000)])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm_fwd_bwd(Cc, HW, silu):
     ops = _ops()
