@@ -554,7 +554,8 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
 struct TileDims {
   int bm, bn;
 };
-constexpr TileDims kTiles[7] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 256}, {256, 128}};
+constexpr TileDims kTiles[10] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128},
+                                {256, 256}, {256, 128}, {256, 128}, {256, 128}, {128, 128}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -661,9 +662,9 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     cfg -= 100;
   }
   if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
-  VN_REQUIRE(cfg >= 1 && cfg <= 6, "gemm: unknown tile_hint %d", d->tile_hint);
+  VN_REQUIRE(cfg >= 1 && cfg <= 9, "gemm: unknown tile_hint %d", d->tile_hint);
   if (cfg == 5 && f32) cfg = 4;  // the 256x256 tile's f32 epilogue staging would not fit in LDS
-  if (cfg == 6 && !dma) cfg = 4;  // the 3-stage ring exists with LDS-DMA only
+  if ((cfg == 6 || cfg == 7) && !dma) cfg = 4;  // the 3-stage ring exists with LDS-DMA only
   long long ws_floats = d->workspace ? d->workspace_bytes / 4 : 0;
   int ks = d->split_k;
   if (ks == 0) ks = select_ksplit(d->M, d->N, d->K, batch, cfg, ws_floats);
@@ -688,6 +689,10 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     case 3: LAUNCH(64, 64, 32, 32);
     case 4: LAUNCH(256, 128, 64, 64);
     case 6: return launch_cfg_ring<256, 128, 64, 64>(g, f32, st);
+    // narrower wave tiles = more waves per SIMD: the loop is latency- rather than bandwidth-limited
+    case 7: return launch_cfg_ring<256, 128, 64, 32>(g, f32, st);  // 16 waves x (64x32), 3-stage ring
+    case 8: LAUNCH(256, 128, 64, 32);                              // 16 waves x (64x32)
+    case 9: LAUNCH(128, 128, 64, 32);                              // 8 waves x (64x32)
     default:
       return dma ? launch_cfg_f16<256, 256, 64, 64, true>(g, st) : launch_cfg_f16<256, 256, 64, 64, false>(g, st);
   }

@@ -127,7 +127,7 @@ class Schedule:
         ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
         return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32)
 
-    def autotune(self, candidates=(1, 2, 3, 4, 5, 6), reps=8):
+    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9), reps=8):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
         tile configuration, with the split-K heuristic and with split-K forced off (the f32 partials
         and the reduce launch are not always worth the extra blocks), and pin the fastest pair.
