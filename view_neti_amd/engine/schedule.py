@@ -55,6 +55,8 @@ class Schedule:
         # f32 scratch for split-K GEMM / q-split attention partials: one per schedule, so two schedules
         # may run concurrently on different streams (bind_workspace() pins it into every launch)
         self.ws = self._buf((16 * 2 ** 20,), torch.float32)
+        self.ws_side = None
+        self._side_stream = None
         if ops._default_ws is None or ops._default_ws.device != torch.device(device, torch.cuda.current_device()):
             ops.set_default_gemm_workspace(torch.empty(16 * 2 ** 20, dtype=torch.float32, device=device))
 
@@ -160,7 +162,7 @@ class Schedule:
                     cache[key] = best
                 kw = dict(f.keywords)
                 kw["tile_hint"], kw["split_k"] = cache[key]
-                lst[idx] = partial(ops.gemm, *f.args, **kw)
+                lst[idx] = self._rebound(f, ops.gemm, kw)
 
     def bind_workspace(self):
         """pin this schedule's own split-K / q-split scratch into every launch that may use one."""
@@ -169,8 +171,24 @@ class Schedule:
                 fn = getattr(f, "func", None)
                 if fn is ops.gemm or fn is ops.attn_bwd_dkv:
                     kw = dict(f.keywords)
-                    kw["workspace"] = self.ws
-                    lst[idx] = partial(fn, *f.args, **kw)
+                    # launches that run on the side stream get their own scratch: they may overlap main-stream GEMMs
+                    kw["workspace"] = self.ws_side if getattr(f, "side", False) else self.ws
+                    lst[idx] = self._rebound(f, fn, kw)
+
+    @staticmethod
+    def _rebound(f, fn, kw):
+        p = partial(fn, *f.args, **kw)
+        if getattr(f, "side", False):
+            p.side = True
+        return p
+
+    def _side(self, launch):
+        """mark a launch as independent of the main chain until the end of the list: it is forked onto a second
+        stream (in a captured graph: a parallel branch) and joined when the list finishes."""
+        launch.side = True
+        if self.ws_side is None:
+            self.ws_side = self._buf((4 * 2 ** 20,), torch.float32)
+        return launch
 
     # ------------------------------------------------------------------ layer builders
     def _gn(self, x: T, name, w, eps, silu):
@@ -297,6 +315,22 @@ class Schedule:
         self.forward_pre()
         self.forward_main()
 
+    def _run(self, lst):
+        side = None
+        main = None
+        for f in lst:
+            if getattr(f, "side", False):
+                if side is None:
+                    if self._side_stream is None:
+                        self._side_stream = torch.cuda.Stream()
+                    side, main = self._side_stream, torch.cuda.current_stream()
+                side.wait_stream(main)  # fork point: everything issued so far
+                with torch.cuda.stream(side):
+                    f()
+            else:
+                f()
+        if side is not None:
+            main.wait_stream(side)  # join
+
     def backward(self):
-        for f in self.bwd:
-            f()
+        self._run(self.bwd)

@@ -205,12 +205,14 @@ class UNetEngine(Schedule):
                               heads, N, L, D, r["scale"], False, O=r["o2"]))
         else:
             bw.append(partial(ops.attn_bwd_delta, do2, r["o2"], delta, B, heads, N, D))
-        dk2 = self._tmp("tdk2", B * L, Cc)
-        dv2 = self._tmp("tdv2", B * L, Cc)
+        # per-layer dK/dV: their projections back to the context gradient are off the critical path (nothing in
+        # the UNet backward reads dctx), so they run as a parallel branch and must not share scratch with later layers
+        dk2 = self._buf((B * L, Cc))
+        dv2 = self._buf((B * L, Cc))
         bw.append(partial(ops.attn_bwd_dkv, r["q2"], q2t, ldn, r["k2"], r["v2"], do2, do2t, ldn, r["lse2"], delta,
                           dk2, dv2, B, heads, N, L, D, r["scale"], False))
-        bw.append(partial(ops.gemm, dk2, r["wk2d"], self.dctx_k[li]))
-        bw.append(partial(ops.gemm, dv2, r["wv2d"], self.dctx_v[li]))
+        bw.append(self._side(partial(ops.gemm, dk2, r["wk2d"], self.dctx_k[li])))
+        bw.append(self._side(partial(ops.gemm, dv2, r["wv2d"], self.dctx_v[li])))
         if not r["need_dx"]:
             return
         dn2 = self._tmp("tA", M, Cc)  # do2 is dead after dq
