@@ -172,3 +172,38 @@ def test_multi_object_mappers_and_segmented_adamw():
           f"seg_step {eng.seg_step.tolist()} opt_step {eng.opt_step.item()}")
     assert err < 0.05
     assert eng.seg_step.tolist() == [5, 1, 4] and eng.opt_step.item() == len(order)
+
+
+def test_full_size_directional_derivative():
+    """BASELINE config 2 at its real size (SD-1.5 shapes, 512x512, bs=4): the CPU oracle cannot run there, so parity
+    is checked through a size-independent property — the mapper gradient produced by the hand-built backward must
+    predict the change of the forward loss along its own direction: (L(p+e*d) - L(p-e*d)) / (2e) == g.d,  d = g/|g|."""
+    from view_neti_amd import synth
+    B, H, W = 4, 512, 512
+    cfg, eng, _, _, _, _ = build("sd15", B, H, W, device_rng=False, lr=1e-3)
+    ph = cfg.clip.vocab_size - 3
+    eng.set_batch(synth.pixel_values(B, H, W), synth.input_ids(B, ph, cfg.clip.vocab_size), torch.full((B,), ph))
+    eng.set_noise(synth.gaussian((B, 4, H // 8, W // 8), 3), synth.gaussian((B, 4, H // 8, W // 8), 4), synth.timesteps(B))
+    eng.forward_backward()
+    torch.cuda.synchronize()
+    loss0 = eng.loss()
+    g = (eng.grads / eng.scaler[0]).clone()
+    gn = float(g.norm())
+    assert math.isfinite(loss0) and math.isfinite(gn) and gn > 0
+    d = g / gn
+    p0 = eng.params.clone()
+    eps = 0.02 / gn if gn > 0.02 else 1.0  # aim at a loss change of ~4e-2 (fp16 noise of the loss is ~1e-4)
+    eps = min(eps, 0.05 * float(p0.norm()))  # but stay in the locally linear regime
+    losses = []
+    for sgn in (+1.0, -1.0):
+        eng.params.copy_(p0 + sgn * eps * d)
+        eng.forward_backward()
+        torch.cuda.synchronize()
+        losses.append(eng.loss())
+    eng.params.copy_(p0)
+    measured = (losses[0] - losses[1]) / (2 * eps)
+    ratio = measured / gn
+    print(f"[full size] loss {loss0:.5f} |g| {gn:.4e} eps {eps:.3e}: L+ {losses[0]:.5f} L- {losses[1]:.5f} "
+          f"directional derivative {measured:.4e} vs |g| -> ratio {ratio:.3f}")
+    assert losses[0] > loss0 > losses[1], "the loss must rise along +g and fall along -g"
+    assert 0.8 < ratio < 1.25
