@@ -103,9 +103,15 @@ class Coach:
         self.checkpoint_handler = CheckpointHandler(
             cfg, self.train_dataset.placeholder_view_tokens, self.placeholder_view_token_ids,
             self.train_dataset.placeholder_object_tokens, self.placeholder_object_token_ids, cfg.log.exp_dir)
+        # every rank draws its own batches (accelerate shards the prepared dataloader across processes,
+        # coach.py:97-99): one shuffling stream per rank; rank 0 of a 1-process run keeps the global generator
+        gen = None
+        if self.world > 1:
+            gen = torch.Generator()
+            gen.manual_seed(parallel.data_seed(cfg.seed, self.rank))
         self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=bs, shuffle=True,
                                                             num_workers=cfg.data.dataloader_num_workers,
-                                                            drop_last=True)
+                                                            drop_last=True, generator=gen)
 
     # ------------------------------------------------------------------ set-up
     def _setup_logging(self):
