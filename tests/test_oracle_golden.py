@@ -157,3 +157,36 @@ def test_ddpm_schedule_and_unet_shapes():
     assert tot(sc.vae_encoder_shapes(sc.sd15().vae)) == 34163664
     assert tot(sc.clip_text_shapes(sc.sd15().clip)) == 123060480
     assert len(sc.cross_attention_order(sc.sd15().unet)) == 16
+
+
+def test_config1_cpu_plumbing_two_steps():
+    """BASELINE.json config 1 in miniature ("2 steps on the CPU path, plumbing, no GPU"): the oracle's whole train step
+    (VAE encode -> add noise -> 16 x text encoder with the mapper -> UNet -> MSE -> autograd -> AdamW) runs twice on the
+    tiny SD shape family with fixed inputs; the second loss on the SAME batch/noise must be lower (the mapper learns)."""
+    from oracle import sd_ref as R
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.text import flatten_mapper_state, unflatten_mapper_state
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    cfg = sc.tiny()
+    B, H, W = 1, 64, 64
+    uw, vw, cw = synth.unet_weights(cfg.unet), synth.vae_weights(cfg.vae), synth.clip_weights(cfg.clip)
+    D = cfg.clip.hidden_size
+    torch.manual_seed(0)
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    sd = init_mapper_state(64, 64, D)
+    ph = cfg.clip.vocab_size - 3
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size)
+    px, t = synth.pixel_values(B, H, W), synth.timesteps(B)
+    eps, noise = synth.gaussian((B, 4, H // 8, W // 8), 3), synth.gaussian((B, 4, H // 8, W // 8), 4)
+    flat = flatten_mapper_state(sd)
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    losses = []
+    for step in (1, 2):
+        p = {k: x.clone().requires_grad_(True) for k, x in unflatten_mapper_state(flat, 64, 64, 2 * D).items()}
+        loss, _ = R.train_step_loss(cfg, uw, vw, cw, p, w_enc, 0.4, px, ids, torch.full((B,), ph), t, eps, noise)
+        loss.backward()
+        g = flatten_mapper_state({k: x.grad for k, x in p.items()})
+        assert torch.isfinite(loss) and torch.isfinite(g).all() and g.abs().sum() > 0
+        flat, m, v = R.adamw_step(flat, g, m, v, step, 4e-3)
+        losses.append(loss.item())
+    assert losses[1] < losses[0], losses
