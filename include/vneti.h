@@ -145,16 +145,16 @@ int vneti_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, const voi
 /* ------------------------------------------------------------------------------------------
  * Fused (flash-style) multi-head attention, head_dim in {40, 64, 80, 160}.
  *   O[b,q,h,:] = softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,:]
- * Q/K/O rows are token rows of [B*N][ld] matrices with head h at column h*D.  V (and for
- * the backward K, Q, dO) are additionally supplied TRANSPOSED per batch: Xt[b][h*D+d][n]
- * with row stride ldt (>= N, multiple of 8, pad columns zero) — see vneti_transpose_f16.
+ * Q/K/V/O (and dO, dQ, dK, dV) rows are token rows of [B*N][ld] matrices with head h at column h*D;
+ * no transposed operand copies are needed: operands an MFMA wants key-/query-major are read
+ * transposed out of the row-major LDS tiles (ds_read_b64_tr_b16).
  * K and V come from separate tensors: this is the XTI contract
  * (models/xti_attention_processor.py:38-42: key from CONTEXT_TENSOR_l, value from
  * CONTEXT_TENSOR_BYPASS_l).  Replaces attn.get_attention_scores + torch.bmm (:48-49)
  * without materialising the score matrix.  lse: f32 [B][H][Nq] (natural log).
  * ------------------------------------------------------------------------------------------ */
-int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long long ldk, const void* Vt,
-                   long long ldvt, void* O, long long ldo, float* lse, int Bn, int H, int Nq,
+int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long long ldk, const void* V,
+                   long long ldv, void* O, long long ldo, float* lse, int Bn, int H, int Nq,
                    int Nk, int D, float scale, int causal, void* stream);
 /* delta[b][h][q] = sum_d dO*O  (f32) */
 int vneti_attn_bwd_delta(const void* dO, long long lddo, const void* O, long long ldo,
@@ -162,17 +162,16 @@ int vneti_attn_bwd_delta(const void* dO, long long lddo, const void* O, long lon
 /* dQ.  With O == NULL, delta is an input (from vneti_attn_bwd_delta).  With O given, the kernel computes
  * delta itself from the dO rows it already holds and WRITES it to `delta` for the dK/dV kernel that
  * follows — one launch fewer per attention. */
-int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, long long ldk, const void* Kt,
-                      long long ldkt, const void* V, long long ldv, const void* dO,
-                      long long lddo, const float* lse, float* delta, const void* O, long long ldo,
-                      void* dQ, long long lddq, int Bn, int H, int Nq, int Nk, int D, float scale,
-                      int causal, void* stream);
-int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, long long ldqt,
-                       const void* K, long long ldk, const void* V, long long ldv,
-                       const void* dO, long long lddo, const void* dOt, long long lddot,
-                       const float* lse, const float* delta, void* dK, long long lddk, void* dV,
-                       long long lddv, int Bn, int H, int Nq, int Nk, int D, float scale,
-                       int causal, float* ws, long long ws_floats, void* stream);
+int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, long long ldk, const void* V,
+                      long long ldv, const void* dO, long long lddo, const float* lse, float* delta,
+                      const void* O, long long ldo, void* dQ, long long lddq, int Bn, int H, int Nq,
+                      int Nk, int D, float scale, int causal, void* stream);
+/* dK, dV.  ws (optional): f32 scratch for the query-split partials of short-key (cross) attention. */
+int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* K, long long ldk, const void* V,
+                       long long ldv, const void* dO, long long lddo, const float* lse,
+                       const float* delta, void* dK, long long lddk, void* dV, long long lddv,
+                       int Bn, int H, int Nq, int Nk, int D, float scale, int causal, float* ws,
+                       long long ws_floats, void* stream);
 /* ws (optional f32 scratch): when the key side is short (cross-attention, Nk = 77) the query
  * range is split across workgroups and the f32 partials are reduced by a second kernel;
  * needs 2*qsplit*Bn*Nk*H*D floats (qsplit <= 32), NULL disables the split. */

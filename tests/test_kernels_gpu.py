@@ -308,23 +308,9 @@ def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
     o_ref.backward(do.float())
 
     qd, kd, vd, dod = (t.to(DEV).view(-1, Cc) for t in (q, k, v, do))
-    ldk = (Nk + 7) // 8 * 8
-    ldq = (Nq + 7) // 8 * 8
-    vt = torch.zeros(Bn, Cc, ldk, dtype=torch.float16, device=DEV)
-    kt = torch.zeros(Bn, Cc, ldk, dtype=torch.float16, device=DEV)
-    qt = torch.zeros(Bn, Cc, ldq, dtype=torch.float16, device=DEV)
-    dot = torch.zeros(Bn, Cc, ldq, dtype=torch.float16, device=DEV)
-    ops.transpose(vd, vt, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk)
-    # the three backward operand copies in one launch (different shapes/batch strides per descriptor)
-    ops.transpose_multi([(kd, kt, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk), (qd, qt, Nq, Cc, Bn, Cc, Nq * Cc, ldq, Cc * ldq),
-                         (dod, dot, Nq, Cc, Bn, Cc, Nq * Cc, ldq, Cc * ldq)])
-    kt1 = torch.zeros_like(kt)
-    ops.transpose(kd, kt1, Nk, Cc, Bn, Cc, Nk * Cc, ldk, Cc * ldk)
-    assert torch.equal(kt, kt1) and torch.equal(qt[:, :, :Nq], q.to(DEV).transpose(1, 2))
-    assert torch.equal(dot[:, :, :Nq], do.to(DEV).transpose(1, 2))
     o = torch.zeros(Bn * Nq, Cc, dtype=torch.float16, device=DEV)
     lse = torch.zeros(Bn, H, Nq, dtype=torch.float32, device=DEV)
-    ops.attn_fwd(qd, kd, vt, o, lse, Bn, H, Nq, Nk, D, scale, causal, ldk)
+    ops.attn_fwd(qd, kd, vd, o, lse, Bn, H, Nq, Nk, D, scale, causal)
     torch.cuda.synchronize()
     tag = f"D{D} H{H} Nq{Nq} Nk{Nk} c{int(causal)}"
     check(f"attn fwd {tag}", o.view(Bn, Nq, Cc), o_ref.detach(), 3e-3)
@@ -335,16 +321,30 @@ def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
     dq = torch.zeros(Bn * Nq, Cc, dtype=torch.float16, device=DEV)
     dk = torch.zeros(Bn * Nk, Cc, dtype=torch.float16, device=DEV)
     dv = torch.zeros(Bn * Nk, Cc, dtype=torch.float16, device=DEV)
-    ops.attn_bwd_dq(qd, kd, kt, ldk, vd, dod, lse, delta, dq, Bn, H, Nq, Nk, D, scale, causal)
+    ops.attn_bwd_dq(qd, kd, vd, dod, lse, delta, dq, Bn, H, Nq, Nk, D, scale, causal)
     # fused variant: delta computed inside the dQ kernel and published for dK/dV
     delta2 = torch.full_like(delta, float("nan"))
     dq2 = torch.zeros_like(dq)
-    ops.attn_bwd_dq(qd, kd, kt, ldk, vd, dod, lse, delta2, dq2, Bn, H, Nq, Nk, D, scale, causal, O=o)
+    ops.attn_bwd_dq(qd, kd, vd, dod, lse, delta2, dq2, Bn, H, Nq, Nk, D, scale, causal, O=o)
     torch.cuda.synchronize()
     check(f"attn delta(in-kernel) {tag}", delta2, delta, 1e-4)
     check(f"attn dq(fused delta) {tag}", dq2, dq, 1e-3)
-    ops.attn_bwd_dkv(qd, qt, ldq, kd, vd, dod, dot, ldq, lse, delta2, dk, dv, Bn, H, Nq, Nk, D, scale, causal)
+    ops.attn_bwd_dkv(qd, kd, vd, dod, lse, delta2, dk, dv, Bn, H, Nq, Nk, D, scale, causal)
     torch.cuda.synchronize()
     check(f"attn dq {tag}", dq.view(Bn, Nq, Cc), qr.grad, 6e-3)
     check(f"attn dk {tag}", dk.view(Bn, Nk, Cc), kr.grad, 6e-3)
     check(f"attn dv {tag}", dv.view(Bn, Nk, Cc), vr.grad, 6e-3)
+
+
+def test_transpose_multi():
+    """several independent batched transposes in one launch (kept for callers that need key-major copies)"""
+    ops = _ops()
+    a = rnd(3, 77, 64, seed=40).to(DEV)
+    b = rnd(2, 130, 40, seed=41).to(DEV)
+    at = torch.zeros(3, 64, 80, dtype=torch.float16, device=DEV)
+    bt = torch.zeros(2, 40, 136, dtype=torch.float16, device=DEV)
+    ops.transpose_multi([(a.view(-1, 64), at, 77, 64, 3, 64, 77 * 64, 80, 64 * 80),
+                         (b.view(-1, 40), bt, 130, 40, 2, 40, 130 * 40, 136, 40 * 136)])
+    torch.cuda.synchronize()
+    assert torch.equal(at[:, :, :77], a.transpose(1, 2)) and torch.equal(bt[:, :, :130], b.transpose(1, 2))
+    assert float(at[:, :, 77:].abs().max()) == 0 and float(bt[:, :, 130:].abs().max()) == 0

@@ -10,25 +10,19 @@ dev = "cuda"
 ops.set_default_gemm_workspace(torch.empty(16 * 2**20, dtype=torch.float32, device=dev))
 q = torch.randn(B * N, C, device=dev).half(); k = torch.randn(B * Nk, C, device=dev).half(); v = torch.randn(B * Nk, C, device=dev).half()
 do = torch.randn(B * N, C, device=dev).half()
-ld = (Nk + 7) // 8 * 8; ldq = (N + 7) // 8 * 8
-vt = torch.zeros(B, C, ld, device=dev, dtype=torch.float16); kt = torch.zeros_like(vt)
-qt = torch.zeros(B, C, ldq, device=dev, dtype=torch.float16); dot = torch.zeros_like(qt)
-ops.transpose(v, vt, Nk, C, B, C, Nk * C, ld, C * ld); ops.transpose(k, kt, Nk, C, B, C, Nk * C, ld, C * ld)
-ops.transpose(q, qt, N, C, B, C, N * C, ldq, C * ldq); ops.transpose(do, dot, N, C, B, C, N * C, ldq, C * ldq)
 o = torch.zeros_like(q); lse = torch.zeros(B, H, N, device=dev); delta = torch.zeros(B, H, N, device=dev)
 dq = torch.zeros_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(k)
 sc = D ** -0.5
 def run():
-    ops.attn_fwd(q, k, vt, o, lse, B, H, N, Nk, D, sc, False, ld)
-    ops.attn_bwd_delta(do, o, delta, B, H, N, D)
-    ops.attn_bwd_dq(q, k, kt, ld, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False, O=o)
-    ops.attn_bwd_dkv(q, qt, ldq, k, v, do, dot, ldq, lse, delta, dk, dv, B, H, N, Nk, D, sc, False)
+    ops.attn_fwd(q, k, v, o, lse, B, H, N, Nk, D, sc, False)
+    ops.attn_bwd_dq(q, k, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False, O=o)
+    ops.attn_bwd_dkv(q, k, v, do, lse, delta, dk, dv, B, H, N, Nk, D, sc, False)
 for _ in range(3): run()
 torch.cuda.synchronize()
 import time
-for name, fn in (("fwd", lambda: ops.attn_fwd(q, k, vt, o, lse, B, H, N, Nk, D, sc, False, ld)),
-                 ("dq", lambda: ops.attn_bwd_dq(q, k, kt, ld, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False, O=o)),
-                 ("dkv", lambda: ops.attn_bwd_dkv(q, qt, ldq, k, v, do, dot, ldq, lse, delta, dk, dv, B, H, N, Nk, D, sc, False))):
+for name, fn in (("fwd", lambda: ops.attn_fwd(q, k, v, o, lse, B, H, N, Nk, D, sc, False)),
+                 ("dq", lambda: ops.attn_bwd_dq(q, k, v, do, lse, delta, dq, B, H, N, Nk, D, sc, False, O=o)),
+                 ("dkv", lambda: ops.attn_bwd_dkv(q, k, v, do, lse, delta, dk, dv, B, H, N, Nk, D, sc, False))):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(10): fn()

@@ -35,14 +35,14 @@ struct Cfg {
 };
 
 struct AttnArgs {
-  const half_t *Q, *K, *V, *Kt, *Vt, *Qt, *dO, *dOt;
+  const half_t *Q, *K, *V, *dO;
   half_t *O, *dQ, *dK, *dV;
   float* lse;
   const float* lse_in;
   const float* delta;
   float* delta_out;      // dQ kernel with O given: delta is computed in-kernel and published here
   const half_t* O_in;    //   (saves the separate delta launch; the dK/dV kernel then runs after dQ)
-  long long ldq, ldk, ldv, ldkt, ldvt, ldqt, ldo, lddo, lddot, lddq, lddk, lddv;
+  long long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int Bn, H, Nq, Nk, D;
   float scale;
   int causal;
@@ -71,12 +71,21 @@ __device__ __forceinline__ half8 cvt8(const f32x16& v, int j) {
   return h;
 }
 
-// A operand (rows = d, k-slots = the 8 keys/queries a lane owns) from a transposed LDS tile.
-__device__ __forceinline__ half8 load_tfrag(const char* base, int row_bytes, int d, int n0) {
-  const char* p = base + d * row_bytes + n0 * 2;
-  half4 lo = as_half4(*reinterpret_cast<const u32x2*>(p));
-  half4 hi = as_half4(*reinterpret_cast<const u32x2*>(p + 16));
-  half8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+// A operand (rows = d, k-slots = the 8 keys/queries a lane owns) read TRANSPOSED out of a ROW-MAJOR
+// [key|query][d] LDS tile with gfx950's ds_read_b64_tr_b16: within a 16-lane group source lane i = 4*jj + qq
+// supplies the address of 4 consecutive d of row (n0 + jj) and the hardware hands lane i the 4 rows jj = 0..3 of
+// column d0 + i (semantics measured with tools/lab/tr_probe.hip).  Lanes 16..31 take the next 16 d.  Two reads
+// give the 8 k-slots (rows n0..n0+3 and n0+8..n0+11) that the P / dS accumulator layout pairs with, so no
+// transposed operand copies (V^T, K^T, Q^T, dO^T) exist anywhere any more.
+typedef short vn_short4 __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ half8 load_tr(const char* tile, int row_bytes, int d0, int n0, int lane) {
+  const int i = lane & 15;
+  const char* p = tile + (n0 + (i >> 2)) * row_bytes + (d0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3)) * 2;
+  typedef __attribute__((address_space(3))) vn_short4* lds_ptr;
+  vn_short4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  vn_short4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 8 * row_bytes));
+  half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+  half8 r = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
   return r;
 }
 
@@ -91,12 +100,12 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
   // each wave owns QW independent 32-query sub-tiles: K/V fragments are read from LDS once and
   // used QW times, and the two softmax/MFMA dependency chains interleave inside the wave
   constexpr int QW = 1;  // 2 sub-tiles per wave measured slower (occupancy 1 wave/SIMD)
-  // when D is padded up to a multiple of 32, row D of the V^T tile is set to ones so the PV MFMA
+  // when D is padded up to a multiple of 32, column D of the V tile is set to ones so the PV MFMA
   // accumulates the softmax denominator for free (it rescales with O as well)
   constexpr bool ONES = C::DB * 32 > D;
   constexpr int L_DB = D / 32, L_R = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_H2 = ((D % 32) >> 2) & 1;
   constexpr int KS_BYTES = 64 * C::ROW;
-  constexpr int VS_BYTES = C::DB * 32 * TROW64;
+  constexpr int VS_BYTES = 64 * C::ROW + 128;  // V tile row-major like K (+ slack: the last rows' d-padding is read)
   constexpr int STAGE = KS_BYTES + VS_BYTES;  // two stages: the next tile is written while this one is read
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
 
   __amdgpu_buffer_rsrc_t rsQ = vn_make_rsrc(a.Q, (uint32_t)((long long)a.Bn * a.Nq * a.ldq * 2));
   __amdgpu_buffer_rsrc_t rsK = vn_make_rsrc(a.K, (uint32_t)((long long)a.Bn * a.Nk * a.ldk * 2));
-  __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.Vt, (uint32_t)((long long)a.Bn * a.H * D * a.ldvt * 2));
+  __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.V, (uint32_t)((long long)a.Bn * a.Nk * a.ldv * 2));
 
   zero_lds(smem, 2 * STAGE);
 
@@ -131,8 +140,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
     }
 
   constexpr int KIT = (64 * C::DCH + 255) / 256;
-  constexpr int VIT = (D * 8 + 255) / 256;
-  u32x4 kreg[KIT], vreg[VIT];
+  u32x4 kreg[KIT], vreg[KIT];
 
   auto issue = [&](int kt) {
     const int key0 = kt * 64;
@@ -141,20 +149,9 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
       int idx = tid + 256 * i;
       int r = idx / C::DCH, c = idx - r * C::DCH;
       int key = key0 + r;
-      uint32_t off = (idx < 64 * C::DCH && key < a.Nk)
-                         ? (uint32_t)((((long long)b * a.Nk + key) * a.ldk + h * D + c * 8) * 2)
-                         : VN_OOB;
-      kreg[i] = vn_buf_load16(rsK, off);
-    }
-#pragma unroll
-    for (int i = 0; i < VIT; ++i) {
-      int idx = tid + 256 * i;
-      int d = idx >> 3, c = idx & 7;
-      int key = key0 + c * 8;
-      uint32_t off = (idx < D * 8 && key < a.ldvt)
-                         ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.ldvt + key) * 2)
-                         : VN_OOB;
-      vreg[i] = vn_buf_load16(rsV, off);
+      const bool ok = idx < 64 * C::DCH && key < a.Nk;
+      kreg[i] = vn_buf_load16(rsK, ok ? (uint32_t)((((long long)b * a.Nk + key) * a.ldk + h * D + c * 8) * 2) : VN_OOB);
+      vreg[i] = vn_buf_load16(rsV, ok ? (uint32_t)((((long long)b * a.Nk + key) * a.ldv + h * D + c * 8) * 2) : VN_OOB);
     }
   };
   auto commit = [&](int buf) {
@@ -164,13 +161,10 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
     for (int i = 0; i < KIT; ++i) {
       int idx = tid + 256 * i;
       int r = idx / C::DCH, c = idx - r * C::DCH;
-      if (idx < 64 * C::DCH) *reinterpret_cast<u32x4*>(Ks + r * C::ROW + c * 16) = kreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < VIT; ++i) {
-      int idx = tid + 256 * i;
-      int d = idx >> 3, c = idx & 7;
-      if (idx < D * 8) *reinterpret_cast<u32x4*>(Vs + d * TROW64 + c * 16) = vreg[i];
+      if (idx < 64 * C::DCH) {
+        *reinterpret_cast<u32x4*>(Ks + r * C::ROW + c * 16) = kreg[i];
+        *reinterpret_cast<u32x4*>(Vs + r * C::ROW + c * 16) = vreg[i];
+      }
     }
   };
 
@@ -195,9 +189,9 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
 
   issue(0);
   __syncthreads();  // LDS zero-fill visible
-  if constexpr (ONES) {
+  if constexpr (ONES) {  // column D of every key row of the V tile (padding that commit() never touches)
     if (tid < 128)
-      *reinterpret_cast<half_t*>(smem + (tid >> 6) * STAGE + KS_BYTES + D * TROW64 + (tid & 63) * 2) = (half_t)1.f;
+      *reinterpret_cast<half_t*>(smem + (tid >> 6) * STAGE + KS_BYTES + (tid & 63) * C::ROW + D * 2) = (half_t)1.f;
   }
   commit(0);
   __syncthreads();
@@ -281,7 +275,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
         for (int u = 0; u < QW; ++u) pf[u] = cvt8(s[u][aa], j);
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
-          half8 vf = load_tfrag(Vs, TROW64, db * 32 + l31, aa * 32 + 16 * j + 4 * h2);
+          half8 vf = load_tr(Vs, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
 #pragma unroll
           for (int u = 0; u < QW; ++u)
             o[u][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[u][db], 0, 0, 0);
@@ -353,8 +347,7 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
   using C = Cfg<D>;
   constexpr int KS_BYTES = 64 * C::ROW;
-  constexpr int KT_BYTES = C::DB * 32 * TROW64;
-  constexpr int STAGE = 2 * KS_BYTES + KT_BYTES;
+  constexpr int STAGE = 2 * KS_BYTES + 128;  // K and V tiles (row-major) + slack for the transposed reads' d-padding
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,7 +361,6 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
   __amdgpu_buffer_rsrc_t rsdO = vn_make_rsrc(a.dO, (uint32_t)((long long)a.Bn * a.Nq * a.lddo * 2));
   __amdgpu_buffer_rsrc_t rsK = vn_make_rsrc(a.K, (uint32_t)((long long)a.Bn * a.Nk * a.ldk * 2));
   __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.V, (uint32_t)((long long)a.Bn * a.Nk * a.ldv * 2));
-  __amdgpu_buffer_rsrc_t rsKt = vn_make_rsrc(a.Kt, (uint32_t)((long long)a.Bn * a.H * D * a.ldkt * 2));
 
   zero_lds(smem, 2 * STAGE);
 
@@ -407,8 +399,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
   }
 
   constexpr int KIT = (64 * C::DCH + 255) / 256;
-  constexpr int TIT = (D * 8 + 255) / 256;
-  u32x4 kreg[KIT], vreg[KIT], treg[TIT];
+  u32x4 kreg[KIT], vreg[KIT];
 
   auto issue = [&](int kt) {
     const int key0 = kt * 64;
@@ -423,21 +414,11 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
       kreg[i] = vn_buf_load16(rsK, offk);
       vreg[i] = vn_buf_load16(rsV, offv);
     }
-#pragma unroll
-    for (int i = 0; i < TIT; ++i) {
-      int idx = tid + 256 * i;
-      int d = idx >> 3, cc = idx & 7;
-      int key = key0 + cc * 8;
-      uint32_t off = (idx < D * 8 && key < a.ldkt)
-                         ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.ldkt + key) * 2)
-                         : VN_OOB;
-      treg[i] = vn_buf_load16(rsKt, off);
-    }
   };
   auto commit = [&](int buf) {
-    char* Ks = smem + buf * STAGE;
-    char* Vs = Ks + KS_BYTES;
-    char* Kts = Ks + 2 * KS_BYTES;
+    // V first, K last: the transposed reads of the K tile run a few halves past its rows' d-padding
+    char* Vs = smem + buf * STAGE;
+    char* Ks = Vs + KS_BYTES;
 #pragma unroll
     for (int i = 0; i < KIT; ++i) {
       int idx = tid + 256 * i;
@@ -446,12 +427,6 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
         *reinterpret_cast<u32x4*>(Ks + r * C::ROW + cc * 16) = kreg[i];
         *reinterpret_cast<u32x4*>(Vs + r * C::ROW + cc * 16) = vreg[i];
       }
-    }
-#pragma unroll
-    for (int i = 0; i < TIT; ++i) {
-      int idx = tid + 256 * i;
-      int d = idx >> 3, cc = idx & 7;
-      if (idx < D * 8) *reinterpret_cast<u32x4*>(Kts + d * TROW64 + cc * 16) = treg[i];
     }
   };
 
@@ -471,9 +446,8 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) issue(kt + 1);
     const int key0 = kt * 64;
-    const char* Ks = smem + (kt & 1) * STAGE;
-    const char* Vs = Ks + KS_BYTES;
-    const char* Kts = Ks + 2 * KS_BYTES;
+    const char* Vs = smem + (kt & 1) * STAGE;
+    const char* Ks = Vs + KS_BYTES;
     const bool need_mask = (key0 + 64 > a.Nk) || a.causal;
 #pragma unroll
     for (int aa = 0; aa < 2; ++aa) {
@@ -506,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(AttnArgs a) {
         half8 pf = cvt8(s, j);
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
-          half8 tf = load_tfrag(Kts, TROW64, db * 32 + l31, aa * 32 + 16 * j + 4 * h2);
+          half8 tf = load_tr(Ks, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
           dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, pf, dq[db], 0, 0, 0);
         }
       }
@@ -545,10 +519,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
   // query tile per barrier interval: 64 rows (two 32-row halves computed back to back with the same
   // registers) where two such blocks still fit a CU's LDS, else 32
   constexpr int QH = DKV_QH(D), QR = 32 * QH;
-  constexpr int TROWQ = QH == 2 ? TROW64 : TROW32;
-  constexpr int QS_BYTES = QR * C::ROW;
-  constexpr int QT_BYTES = C::DB * 32 * TROWQ;
-  constexpr int STAGE = 2 * QS_BYTES + 2 * QT_BYTES + 8 * QR;
+  constexpr int QS_BYTES = QR * C::ROW + 128;  // row-major Q / dO tiles (+ slack: transposed reads touch the d-padding)
+  constexpr int STAGE = 2 * QS_BYTES + 8 * QR;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -564,8 +536,6 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
   __amdgpu_buffer_rsrc_t rsdO = vn_make_rsrc(a.dO, (uint32_t)((long long)a.Bn * a.Nq * a.lddo * 2));
   __amdgpu_buffer_rsrc_t rsK = vn_make_rsrc(a.K, (uint32_t)((long long)a.Bn * a.Nk * a.ldk * 2));
   __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.V, (uint32_t)((long long)a.Bn * a.Nk * a.ldv * 2));
-  __amdgpu_buffer_rsrc_t rsQt = vn_make_rsrc(a.Qt, (uint32_t)((long long)a.Bn * a.H * D * a.ldqt * 2));
-  __amdgpu_buffer_rsrc_t rsdOt = vn_make_rsrc(a.dOt, (uint32_t)((long long)a.Bn * a.H * D * a.lddot * 2));
 
   zero_lds(smem, 2 * STAGE);
 
@@ -582,9 +552,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
   const float c = a.scale * LOG2E;
 
   constexpr int QIT = (QR * C::DCH + 255) / 256;
-  constexpr int TCH = QR / 8;  // 16-byte chunks per transposed row
-  constexpr int TIT = (D * TCH + 255) / 256;
-  u32x4 qreg[QIT], doreg[QIT], qtreg[TIT], dotreg[TIT];
+  u32x4 qreg[QIT], doreg[QIT];
   float lreg = INFINITY, dreg = 0.f;
 
   auto issue = [&](int qt) {
@@ -600,21 +568,6 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
       qreg[i] = vn_buf_load16(rsQ, o1);
       doreg[i] = vn_buf_load16(rsdO, o2);
     }
-#pragma unroll
-    for (int i = 0; i < TIT; ++i) {
-      int idx = tid + 256 * i;
-      int d = idx / TCH, cc = idx % TCH;
-      int qq = q0 + cc * 8;
-      bool okr = idx < D * TCH;
-      uint32_t o1 = (okr && qq < a.ldqt)
-                        ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.ldqt + qq) * 2)
-                        : VN_OOB;
-      uint32_t o2 = (okr && qq < a.lddot)
-                        ? (uint32_t)(((((long long)b * a.H + h) * D + d) * a.lddot + qq) * 2)
-                        : VN_OOB;
-      qtreg[i] = vn_buf_load16(rsQt, o1);
-      dotreg[i] = vn_buf_load16(rsdOt, o2);
-    }
     if (tid < QR) {
       int qq = q0 + tid;
       if (qq < a.Nq) {
@@ -629,9 +582,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
   auto commit = [&](int buf) {
     char* Qs = smem + buf * STAGE;
     char* dOs = Qs + QS_BYTES;
-    char* Qts = Qs + 2 * QS_BYTES;
-    char* dOts = Qts + QT_BYTES;
-    float* lses = reinterpret_cast<float*>(dOts + QT_BYTES);
+    float* lses = reinterpret_cast<float*>(dOs + QS_BYTES);
     float* dels = lses + QR;
 #pragma unroll
     for (int i = 0; i < QIT; ++i) {
@@ -640,15 +591,6 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
       if (idx < QR * C::DCH) {
         *reinterpret_cast<u32x4*>(Qs + r * C::ROW + cc * 16) = qreg[i];
         *reinterpret_cast<u32x4*>(dOs + r * C::ROW + cc * 16) = doreg[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TIT; ++i) {
-      int idx = tid + 256 * i;
-      int d = idx / TCH, cc = idx % TCH;
-      if (idx < D * TCH) {
-        *reinterpret_cast<u32x4*>(Qts + d * TROWQ + cc * 16) = qtreg[i];
-        *reinterpret_cast<u32x4*>(dOts + d * TROWQ + cc * 16) = dotreg[i];
       }
     }
     if (tid < QR) {
@@ -680,9 +622,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
     const int q0 = qt * QR;
     const char* Qs = smem + ((qt - qt0) & 1) * STAGE;
     const char* dOs = Qs + QS_BYTES;
-    const char* Qts = Qs + 2 * QS_BYTES;
-    const char* dOts = Qts + QT_BYTES;
-    const float* lses = reinterpret_cast<const float*>(dOts + QT_BYTES);
+    const float* lses = reinterpret_cast<const float*>(dOs + QS_BYTES);
     const float* dels = lses + QR;
 
 #pragma unroll
@@ -723,8 +663,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(AttnArgs a) {
         half8 dsf = cvt8(dp, j);
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
-          half8 dot = load_tfrag(dOts, TROWQ, db * 32 + l31, hq * 32 + 16 * j + 4 * h2);
-          half8 qtf = load_tfrag(Qts, TROWQ, db * 32 + l31, hq * 32 + 16 * j + 4 * h2);
+          half8 dot = load_tr(dOs, C::ROW, db * 32, hq * 32 + 16 * j + 4 * h2, lane);
+          half8 qtf = load_tr(Qs, C::ROW, db * 32, hq * 32 + 16 * j + 4 * h2, lane);
           dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf, dv[db], 0, 0, 0);
           dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf, dk[db], 0, 0, 0);
         }
@@ -813,23 +753,23 @@ int check_common(int Bn, int H, int Nq, int Nk, int D) {
 
 }  // namespace
 
-extern "C" int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long long ldk, const void* Vt,
-                              long long ldvt, void* O, long long ldo, float* lse, int Bn, int H, int Nq, int Nk,
+extern "C" int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long long ldk, const void* V,
+                              long long ldv, void* O, long long ldo, float* lse, int Bn, int H, int Nq, int Nk,
                               int D, float scale, int causal, void* stream) {
   int rc = check_common(Bn, H, Nq, Nk, D);
   VN_REQUIRE(rc == 0, "attn_fwd: unsupported shape B=%d H=%d Nq=%d Nk=%d D=%d", Bn, H, Nq, Nk, D);
-  VN_REQUIRE(Q && K && Vt && O, "attn_fwd: null pointer");
-  VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Nk, "attn_fwd: bad strides");
+  VN_REQUIRE(Q && K && V && O, "attn_fwd: null pointer");
+  VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attn_fwd: bad strides");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.Q = (const half_t*)Q;
   a.K = (const half_t*)K;
-  a.Vt = (const half_t*)Vt;
+  a.V = (const half_t*)V;
   a.O = (half_t*)O;
   a.lse = lse;
   a.ldq = ldq;
   a.ldk = ldk;
-  a.ldvt = ldvt;
+  a.ldv = ldv;
   a.ldo = ldo;
   a.Bn = Bn;
   a.H = H;
@@ -853,23 +793,21 @@ extern "C" int vneti_attn_bwd_delta(const void* dO, long long lddo, const void* 
   return vneti_check_launch("attn_bwd_delta");
 }
 
-extern "C" int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, long long ldk, const void* Kt,
-                                 long long ldkt, const void* V, long long ldv, const void* dO, long long lddo,
+extern "C" int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, long long ldk, const void* V,
+                                 long long ldv, const void* dO, long long lddo,
                                  const float* lse, float* delta, const void* O, long long ldo, void* dQ,
                                  long long lddq, int Bn, int H, int Nq, int Nk, int D, float scale, int causal,
                                  void* stream) {
   int rc = check_common(Bn, H, Nq, Nk, D);
   VN_REQUIRE(rc == 0, "attn_bwd_dq: unsupported shape B=%d H=%d Nq=%d Nk=%d D=%d", Bn, H, Nq, Nk, D);
-  VN_REQUIRE(Q && K && Kt && V && dO && lse && delta && dQ, "attn_bwd_dq: null pointer");
+  VN_REQUIRE(Q && K && V && dO && lse && delta && dQ, "attn_bwd_dq: null pointer");
   VN_REQUIRE(!O || ldo % 8 == 0, "attn_bwd_dq: ldo must be a multiple of 8");
-  VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldkt % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 &&
-                 ldkt >= Nk,
+  VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0,
              "attn_bwd_dq: bad strides");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.Q = (const half_t*)Q;
   a.K = (const half_t*)K;
-  a.Kt = (const half_t*)Kt;
   a.V = (const half_t*)V;
   a.dO = (const half_t*)dO;
   a.dQ = (half_t*)dQ;
@@ -880,7 +818,6 @@ extern "C" int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, lo
   a.ldo = ldo;
   a.ldq = ldq;
   a.ldk = ldk;
-  a.ldkt = ldkt;
   a.ldv = ldv;
   a.lddo = lddo;
   a.lddq = lddq;
@@ -897,36 +834,30 @@ extern "C" int vneti_attn_bwd_dq(const void* Q, long long ldq, const void* K, lo
   return vneti_check_launch("attn_bwd_dq");
 }
 
-extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* Qt, long long ldqt, const void* K,
-                                  long long ldk, const void* V, long long ldv, const void* dO, long long lddo,
-                                  const void* dOt, long long lddot, const float* lse, const float* delta,
+extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* K, long long ldk, const void* V,
+                                  long long ldv, const void* dO, long long lddo, const float* lse, const float* delta,
                                   void* dK, long long lddk, void* dV, long long lddv, int Bn, int H, int Nq,
                                   int Nk, int D, float scale, int causal, float* ws, long long ws_floats,
                                   void* stream) {
   int rc = check_common(Bn, H, Nq, Nk, D);
   VN_REQUIRE(rc == 0, "attn_bwd_dkv: unsupported shape B=%d H=%d Nq=%d Nk=%d D=%d", Bn, H, Nq, Nk, D);
-  VN_REQUIRE(Q && Qt && K && V && dO && dOt && lse && delta && dK && dV, "attn_bwd_dkv: null pointer");
-  VN_REQUIRE(ldq % 8 == 0 && ldqt % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddot % 8 == 0 &&
-                 lddk % 4 == 0 && lddv % 4 == 0 && ldqt >= Nq && lddot >= Nq,
+  VN_REQUIRE(Q && K && V && dO && lse && delta && dK && dV, "attn_bwd_dkv: null pointer");
+  VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
              "attn_bwd_dkv: bad strides");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.Q = (const half_t*)Q;
-  a.Qt = (const half_t*)Qt;
   a.K = (const half_t*)K;
   a.V = (const half_t*)V;
   a.dO = (const half_t*)dO;
-  a.dOt = (const half_t*)dOt;
   a.dK = (half_t*)dK;
   a.dV = (half_t*)dV;
   a.lse_in = lse;
   a.delta = delta;
   a.ldq = ldq;
-  a.ldqt = ldqt;
   a.ldk = ldk;
   a.ldv = ldv;
   a.lddo = lddo;
-  a.lddot = lddot;
   a.lddk = lddk;
   a.lddv = lddv;
   a.Bn = Bn;

@@ -216,7 +216,6 @@ class TextEngine(Schedule):
                          self.pos_view, self.bv["word"] if self.bv else None, x, nl, B, L, D))
         self.x0 = x
         self.layers = []
-        ldn = rup(L, 8)
         act = ops.ACT_QUICK_GELU if cfg.act == "quick_gelu" else ops.ACT_GELU
         for i in range(cfg.num_layers):
             p = f"text_model.encoder.layers.{i}."
@@ -230,11 +229,9 @@ class TextEngine(Schedule):
             qkv = self._buf((Rt, 3 * D))
             f.append(partial(ops.gemm, n1, r["wqkv"], qkv, bias=r_bqkv))
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-            vt = self._buf((R, D, ldn))
-            f.append(partial(ops.transpose, v, vt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn))
             o = self._buf((Rt, D))
             lse = self._buf((R, H, L), torch.float32)
-            f.append(partial(ops.attn_fwd, q, k, vt, o, lse, R, H, L, L, hd, hd ** -0.5, True, ldn))
+            f.append(partial(ops.attn_fwd, q, k, v, o, lse, R, H, L, L, hd, hd ** -0.5, True))
             r["wo"], bo_ = self._w16(w[p + "self_attn.out_proj.weight"]), self._w32(w[p + "self_attn.out_proj.bias"])
             x_mid = self._buf((Rt, D), torch.float32)
             f.append(partial(ops.gemm, o, r["wo"], x_mid, bias=bo_, resid=x))
@@ -247,7 +244,7 @@ class TextEngine(Schedule):
             f.append(partial(ops.act_fwd, f1, a1, act))
             x_out = self._buf((Rt, D), torch.float32)
             f.append(partial(ops.gemm, a1, r["w2"], x_out, bias=b2, resid=x_mid))
-            r.update(qkv=qkv, o=o, lse=lse, x_mid=x_mid, f1=f1, ldn=ldn)
+            r.update(qkv=qkv, o=o, lse=lse, x_mid=x_mid, f1=f1)
             if self.need_backward:
                 tr = lambda t: self._w16(t.t())
                 r["w2d"], r["w1d"] = tr(w[p + "mlp.fc2.weight"]), tr(w[p + "mlp.fc1.weight"])
@@ -283,7 +280,6 @@ class TextEngine(Schedule):
         # writes that f16 copy itself, only the very first one (out of text_final_bwd) needs a cast launch
         bw.append(partial(ops.cast_f32_f16, dx, g16))
         for r in reversed(self.layers):
-            ldn = r["ldn"]
             qkv = r["qkv"]
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             da = self._tmp("cA", Rt, F)
@@ -296,20 +292,12 @@ class TextEngine(Schedule):
             do = self._tmp("cD", Rt, D)
             bw.append(partial(ops.gemm, g16, r["wod"], do))
             delta = self._tmp("cdelta", R * H, L, torch.float32)
-            qt = self._tmp("cQt", R * D, ldn)
-            kt = self._tmp("cKt", R * D, ldn)
-            dot = self._tmp("cdOt", R * D, ldn)
-            bw.append(partial(ops.transpose_multi, [(q, qt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn),
-                                                    (k, kt, L, D, R, 3 * D, L * 3 * D, ldn, D * ldn),
-                                                    (do, dot, L, D, R, D, L * D, ldn, D * ldn)]))
             dqkv = self._tmp("cE", Rt, 3 * D)
             dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
             sc_ = hd ** -0.5
             # dQ first: it also produces delta = rowsum(dO o O) for the dK/dV kernel
-            bw.append(partial(ops.attn_bwd_dq, q, k, kt, ldn, v, do, r["lse"], delta, dq, R, H, L, L, hd, sc_, True,
-                              O=r["o"]))
-            bw.append(partial(ops.attn_bwd_dkv, q, qt, ldn, k, v, do, dot, ldn, r["lse"], delta, dk, dv, R, H, L, L,
-                              hd, sc_, True))
+            bw.append(partial(ops.attn_bwd_dq, q, k, v, do, r["lse"], delta, dq, R, H, L, L, hd, sc_, True, O=r["o"]))
+            bw.append(partial(ops.attn_bwd_dkv, q, k, v, do, r["lse"], delta, dk, dv, R, H, L, L, hd, sc_, True))
             dn1 = self._tmp("cC", Rt, D)
             bw.append(partial(ops.gemm, dqkv, r["wqkvd"], dn1))
             bw.append(partial(self._ln_bwd, r["ln1"], dn1, dx, dxm, g16))     # dx_in = LN1'(dn1) + dx_mid

@@ -108,12 +108,9 @@ class UNetEngine(Schedule):
         qkv = self._buf((M, 3 * Cc))
         self.fwd.append(partial(ops.gemm, n1, r["wqkv"], qkv))
         q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
-        ldn = _rup(N, 8)
-        vt = self._buf((B, Cc, ldn))
-        self.fwd.append(partial(ops.transpose, v, vt, N, Cc, B, 3 * Cc, N * 3 * Cc, ldn, Cc * ldn))
         o1 = self._buf((M, Cc))
         lse1 = self._buf((B, heads, N), torch.float32)
-        self.fwd.append(partial(ops.attn_fwd, q, k, vt, o1, lse1, B, heads, N, N, D, scale, False, ldn))
+        self.fwd.append(partial(ops.attn_fwd, q, k, v, o1, lse1, B, heads, N, N, D, scale, False))
         r["wo1"], bo1 = self._w16(w[t + "attn1.to_out.0.weight"]), self._w32(w[t + "attn1.to_out.0.bias"])
         h1 = self._buf((M, Cc))
         self.fwd.append(partial(ops.gemm, o1, r["wo1"], h1, bias=bo1, resid=h0))
@@ -129,12 +126,9 @@ class UNetEngine(Schedule):
         # K/V of the XTI contexts depend only on the text side: prologue launches (overlappable)
         self.fwd_pre.append(partial(ops.gemm, self.ctx_k[layer_idx], r["wk2"], k2))
         self.fwd_pre.append(partial(ops.gemm, self.ctx_v[layer_idx], r["wv2"], v2))
-        ldl = _rup(L, 8)
-        v2t = self._buf((B, Cc, ldl))
-        self.fwd_pre.append(partial(ops.transpose, v2, v2t, L, Cc, B, Cc, L * Cc, ldl, Cc * ldl))
         o2 = self._buf((M, Cc))
         lse2 = self._buf((B, heads, N), torch.float32)
-        self.fwd.append(partial(ops.attn_fwd, q2, k2, v2t, o2, lse2, B, heads, N, L, D, scale, False, ldl))
+        self.fwd.append(partial(ops.attn_fwd, q2, k2, v2, o2, lse2, B, heads, N, L, D, scale, False))
         r["wo2"], bo2 = self._w16(w[t + "attn2.to_out.0.weight"]), self._w32(w[t + "attn2.to_out.0.bias"])
         h2 = self._buf((M, Cc))
         self.fwd.append(partial(ops.gemm, o2, r["wo2"], h2, bias=bo2, resid=h1))
@@ -152,7 +146,7 @@ class UNetEngine(Schedule):
         out = T(out_view if out_view is not None else self._buf((M, Cc)))
         self.fwd.append(partial(ops.gemm, h3, r["w_out"], out.v, bias=b_out, resid=x.v))
         r.update(out=out, h0=h0, h1=h1, h2=h2, qkv=qkv, o1=o1, lse1=lse1, q2=q2, k2=k2, v2=v2, o2=o2, lse2=lse2,
-                 p=p, ldn=ldn, ldl=ldl)
+                 p=p)
         if self.need_backward:
             tr = lambda a: self._w16(a.t())
             r["wk2d"], r["wv2d"] = tr(w[t + "attn2.to_k.weight"]), tr(w[t + "attn2.to_v.weight"])
@@ -189,28 +183,19 @@ class UNetEngine(Schedule):
         do2 = self._tmp("tA", M, Cc)  # dh3 is dead
         bw.append(partial(ops.gemm, dh2, r["wo2d"], do2))
         delta = self._tmp("tdelta", B * heads, N, torch.float32)
-        ldn, ldl = r["ldn"], r["ldl"]
-        q2t = self._tmp("tQt", B * Cc, ldn)
-        do2t = self._tmp("tdOt", B * Cc, ldn)
-        k2t = self._tmp("tK2t", B * Cc, ldl)
         dq2 = self._tmp("tD", M, Cc)  # dn3 is dead
-        # the transposed operand copies of this attention in ONE launch; delta = rowsum(dO o O) comes out of
-        # the dQ kernel, which therefore runs before dK/dV
-        tr = [(r["q2"], q2t, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn), (do2, do2t, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn)]
+        # delta = rowsum(dO o O) comes out of the dQ kernel, which therefore runs before dK/dV
         if r["need_dx"]:
-            tr.append((r["k2"], k2t, L, Cc, B, Cc, L * Cc, ldl, Cc * ldl))
-        bw.append(partial(ops.transpose_multi, tr))
-        if r["need_dx"]:
-            bw.append(partial(ops.attn_bwd_dq, r["q2"], r["k2"], k2t, ldl, r["v2"], do2, r["lse2"], delta, dq2, B,
-                              heads, N, L, D, r["scale"], False, O=r["o2"]))
+            bw.append(partial(ops.attn_bwd_dq, r["q2"], r["k2"], r["v2"], do2, r["lse2"], delta, dq2, B, heads, N, L, D,
+                              r["scale"], False, O=r["o2"]))
         else:
             bw.append(partial(ops.attn_bwd_delta, do2, r["o2"], delta, B, heads, N, D))
         # per-layer dK/dV: their projections back to the context gradient are off the critical path (nothing in
         # the UNet backward reads dctx), so they run as a parallel branch and must not share scratch with later layers
         dk2 = self._buf((B * L, Cc))
         dv2 = self._buf((B * L, Cc))
-        bw.append(partial(ops.attn_bwd_dkv, r["q2"], q2t, ldn, r["k2"], r["v2"], do2, do2t, ldn, r["lse2"], delta,
-                          dk2, dv2, B, heads, N, L, D, r["scale"], False))
+        bw.append(partial(ops.attn_bwd_dkv, r["q2"], r["k2"], r["v2"], do2, r["lse2"], delta, dk2, dv2, B, heads, N, L,
+                          D, r["scale"], False))
         bw.append(self._side(partial(ops.gemm, dk2, r["wk2d"], self.dctx_k[li])))
         bw.append(self._side(partial(ops.gemm, dv2, r["wv2d"], self.dctx_v[li])))
         if not r["need_dx"]:
@@ -224,18 +209,12 @@ class UNetEngine(Schedule):
         bw.append(partial(ops.gemm, dh1, r["wo1d"], do1))
         qkv = r["qkv"]
         q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
-        qt = self._tmp("tQt", B * Cc, ldn)
-        dot = self._tmp("tdOt", B * Cc, ldn)
-        kt = self._tmp("tKt", B * Cc, ldn)
-        bw.append(partial(ops.transpose_multi, [(q, qt, N, Cc, B, 3 * Cc, N * 3 * Cc, ldn, Cc * ldn),
-                                                (do1, dot, N, Cc, B, Cc, N * Cc, ldn, Cc * ldn),
-                                                (k, kt, N, Cc, B, 3 * Cc, N * 3 * Cc, ldn, Cc * ldn)]))
         dqkv = self._tmp("tC", M, 3 * Cc)  # dp is dead
         dq, dk, dv = dqkv[:, :Cc], dqkv[:, Cc:2 * Cc], dqkv[:, 2 * Cc:]
-        bw.append(partial(ops.attn_bwd_dq, q, k, kt, ldn, v, do1, r["lse1"], delta, dq, B, heads, N, N, D,
-                          r["scale"], False, O=r["o1"]))
-        bw.append(partial(ops.attn_bwd_dkv, q, qt, ldn, k, v, do1, dot, ldn, r["lse1"], delta, dk, dv, B, heads, N, N,
-                          D, r["scale"], False))
+        bw.append(partial(ops.attn_bwd_dq, q, k, v, do1, r["lse1"], delta, dq, B, heads, N, N, D, r["scale"], False,
+                          O=r["o1"]))
+        bw.append(partial(ops.attn_bwd_dkv, q, k, v, do1, r["lse1"], delta, dk, dv, B, heads, N, N, D, r["scale"],
+                          False))
         dn1 = self._tmp("tD", M, Cc)
         bw.append(partial(ops.gemm, dqkv, r["wqkvd"], dn1))
         dh0 = self._tmp("tE", M, Cc)  # dh2 is dead

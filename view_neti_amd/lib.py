@@ -127,9 +127,9 @@ SIGNATURES = {
     "attn_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_int,
                  c_f, c_int, c_vp],
     "attn_bwd_delta": [c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_vp],
-    "attn_bwd_dq": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll,
+    "attn_bwd_dq": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll,
                     c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
-    "attn_bwd_dkv": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp,
+    "attn_bwd_dkv": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp,
                      c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp, c_ll, c_vp],
     "softmax_rows_f16": [c_vp, c_ll, c_int, c_int, c_vp],
     "add_f16": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_vp],

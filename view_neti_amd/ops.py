@@ -136,8 +136,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, accum=None, f16_copy=None):
             rows, Cc, stream())
 
 
-def attn_fwd(Q, K, Vt, O, lse, Bn, H, Nq, Nk, D, scale, causal, ldvt):
-    _l.call("attn_fwd", _p(Q), _ld(Q), _p(K), _ld(K), _p(Vt), ldvt, _p(O), _ld(O), _p(lse), Bn, H, Nq, Nk, D,
+def attn_fwd(Q, K, V, O, lse, Bn, H, Nq, Nk, D, scale, causal):
+    _l.call("attn_fwd", _p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(O), _ld(O), _p(lse), Bn, H, Nq, Nk, D,
             scale, 1 if causal else 0, stream())
 
 
@@ -145,19 +145,18 @@ def attn_bwd_delta(dO, O, delta, Bn, H, Nq, D):
     _l.call("attn_bwd_delta", _p(dO), _ld(dO), _p(O), _ld(O), _p(delta), Bn, H, Nq, D, stream())
 
 
-def attn_bwd_dq(Q, K, Kt, ldkt, V, dO, lse, delta, dQ, Bn, H, Nq, Nk, D, scale, causal, O=None):
+def attn_bwd_dq(Q, K, V, dO, lse, delta, dQ, Bn, H, Nq, Nk, D, scale, causal, O=None):
     """O given: delta is computed inside the kernel and written to `delta` (no attn_bwd_delta launch)."""
-    _l.call("attn_bwd_dq", _p(Q), _ld(Q), _p(K), _ld(K), _p(Kt), ldkt, _p(V), _ld(V), _p(dO), _ld(dO),
-            _p(lse), _p(delta), _p(O), _ld(O) if O is not None else 0, _p(dQ), _ld(dQ), Bn, H, Nq, Nk, D, scale,
-            1 if causal else 0, stream())
+    _l.call("attn_bwd_dq", _p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO), _p(lse), _p(delta),
+            _p(O), _ld(O) if O is not None else 0, _p(dQ), _ld(dQ), Bn, H, Nq, Nk, D, scale, 1 if causal else 0,
+            stream())
 
 
-def attn_bwd_dkv(Q, Qt, ldqt, K, V, dO, dOt, lddot, lse, delta, dK, dV, Bn, H, Nq, Nk, D, scale, causal,
-                 workspace=None):
+def attn_bwd_dkv(Q, K, V, dO, lse, delta, dK, dV, Bn, H, Nq, Nk, D, scale, causal, workspace=None):
     ws = workspace if workspace is not None else _default_ws
-    _l.call("attn_bwd_dkv", _p(Q), _ld(Q), _p(Qt), ldqt, _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO),
-            _p(dOt), lddot, _p(lse), _p(delta), _p(dK), _ld(dK), _p(dV), _ld(dV), Bn, H, Nq, Nk, D, scale,
-            1 if causal else 0, _p(ws), ws.numel() if ws is not None else 0, stream())
+    _l.call("attn_bwd_dkv", _p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO), _p(lse), _p(delta),
+            _p(dK), _ld(dK), _p(dV), _ld(dV), Bn, H, Nq, Nk, D, scale, 1 if causal else 0, _p(ws),
+            ws.numel() if ws is not None else 0, stream())
 
 
 def softmax_rows(x, rows, cols):
