@@ -78,6 +78,17 @@ typedef struct vneti_gemm_desc {
   void* workspace;
   long long workspace_bytes;
   int split_k;
+  /* f16-output epilogue extensions (non-batched), applied after bias/act/rowadd/resid:
+     gate: value *= act'(gate_src[m][n]) (gate_act 1..3) -- the activation backward of a saved
+     pre-activation tensor fused into the producing dgrad GEMM (transformers CLIPMLP backward);
+     C2: a second f16 output C2[m][n] = act2(value written to C) (fc1 writes both the
+     pre-activation kept for backward and the activated tensor). */
+  const void* gate_src;
+  long long ld_gate;
+  int gate_act;
+  void* C2;
+  long long ldc2;
+  int act2;
 } vneti_gemm_desc;
 
 int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream);

@@ -120,6 +120,33 @@ def test_gemm_split_k(split, f32):
     check(f"gemm split_k={split} f32={f32}", out, ref, 2e-3)
 
 
+@pytest.mark.parametrize("act", [1, 2, 3])
+@pytest.mark.parametrize("split", [1, 3])
+@pytest.mark.parametrize("N", [328, 324])
+def test_gemm_gate_and_second_output(act, split, N):
+    """epilogue extensions of the CLIP MLP: out = (A@B^T + bias) * act'(pre), out2 = act2(out)
+    (transformers CLIPMLP forward/backward, modeling_clip.py) in the fused and the split-K reduce epilogue."""
+    ops = _ops()
+    M, K = 200, 64 * 6
+    A = rnd(M, K, seed=51)
+    B = rnd(N, K, scale=1.0 / math.sqrt(K), seed=52)
+    bias = rnd(N, seed=53, dtype=torch.float32)
+    ldp = 336
+    pre = rnd(M, ldp, seed=54, scale=1.5)
+    ws = torch.empty(8 * M * N, dtype=torch.float32, device=DEV)
+    out = torch.zeros(M, ldp, dtype=torch.float16, device=DEV)[:, :N]
+    out2 = torch.zeros(M, ldp, dtype=torch.float16, device=DEV)[:, :N]
+    ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), gate=pre.to(DEV)[:, :N], gate_act=act, out2=out2, act2=act,
+             workspace=ws, split_k=split, tile_hint=3)
+    torch.cuda.synchronize()
+    x = pre[:, :N].float().requires_grad_(True)
+    fn = {1: F.silu, 2: lambda t: t * torch.sigmoid(1.702 * t), 3: F.gelu}[act]
+    fn(x).sum().backward()
+    ref = ((A.float() @ B.float().t() + bias).half().float() * x.grad).half().float()
+    check(f"gemm gate act{act} split{split}", out, ref, 2e-3)
+    check(f"gemm out2 act{act} split{split}", out2, fn(out.float().cpu()), 1e-3)
+
+
 # ------------------------------------------------------------------------------------------ conv
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()

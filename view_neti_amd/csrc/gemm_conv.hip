@@ -38,6 +38,10 @@ struct GemmArgs {
   const half_t* rowadd;
   const void* resid;
   float* ws;
+  const half_t* gate_src;
+  half_t* C2;
+  long long ld_gate, ldc2;
+  int gate_act, act2;
   long long lda, ldb, ldc, ld_rowadd, ldr;
   long long strideA, strideB, strideC;
   uint32_t a_bytes, b_bytes;
@@ -61,6 +65,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case 3: return vn_gelu_erf(v);
     default: return v;
   }
+}
+// d act(x) / dx
+__device__ __forceinline__ float act_grad(float f, int act) {
+  if (act == 2) {
+    float s = vn_sigmoid(1.702f * f);
+    return s * (1.f + 1.702f * f * (1.f - s));
+  } else if (act == 3) {
+    float cdf = 0.5f * (1.f + erff(f * 0.70710678118654752f));
+    return cdf + f * 0.3989422804014327f * __expf(-0.5f * f * f);
+  }
+  float s = vn_sigmoid(f);
+  return s * (1.f + f * (1.f - s));
 }
 
 // LDS tile of R rows x 64 halfs (128 B rows), 16-byte chunks XOR-swizzled so that a
@@ -451,13 +467,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
         }
+        if (g.gate_src) {
+          half8 pre = *reinterpret_cast<const half8*>(g.gate_src + (long long)m * g.ld_gate + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)pre[e], g.gate_act));
+        }
         *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
+        if (g.C2) {
+          half8 o2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o2[e] = (half_t)apply_act((float)v[e], g.act2);
+          *reinterpret_cast<half8*>(g.C2 + (long long)m * g.ldc2 + n) = o2;
+        }
       } else {
         for (int e = 0; e < 8 && n + e < g.N; ++e) {
           float x = (float)v[e];
           if (radd) x = (float)(half_t)(x + (float)radd[e]);
-          if (Rb) x += (float)Rb[(long long)m * g.ldr + n + e];
+          if (Rb) x = (float)(half_t)(x + (float)Rb[(long long)m * g.ldr + n + e]);
+          if (g.gate_src) x = (float)(half_t)(x * act_grad((float)g.gate_src[(long long)m * g.ld_gate + n + e], g.gate_act));
           Cb[(long long)m * g.ldc + n + e] = (half_t)x;
+          if (g.C2) g.C2[(long long)m * g.ldc2 + n + e] = (half_t)apply_act((float)(half_t)x, g.act2);
         }
       }
     }
@@ -497,8 +526,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
       x = (float)(half_t)x;
       if (g.rowadd) x = (float)(half_t)(x + (float)g.rowadd[(long long)(m / g.rows_per_group) * g.ld_rowadd + c + e]);
       if (g.resid)
-        x += (float)reinterpret_cast<const half_t*>(g.resid)[(long long)bz * g.strideC + (long long)m * g.ldr + c + e];
+        x = (float)(half_t)(x + (float)reinterpret_cast<const half_t*>(g.resid)[(long long)bz * g.strideC + (long long)m * g.ldr + c + e]);
+      if (g.gate_src) x = (float)(half_t)(x * act_grad((float)g.gate_src[(long long)m * g.ld_gate + c + e], g.gate_act));
       reinterpret_cast<half_t*>(g.C)[(long long)bz * g.strideC + (long long)m * g.ldc + c + e] = (half_t)x;
+      if (g.C2) g.C2[(long long)m * g.ldc2 + c + e] = (half_t)apply_act((float)(half_t)x, g.act2);
     }
   }
 }
@@ -601,6 +632,12 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   g.bias = d->bias;
   g.rowadd = (const half_t*)d->rowadd;
   g.resid = d->resid;
+  g.gate_src = (const half_t*)d->gate_src;
+  g.ld_gate = d->ld_gate;
+  g.gate_act = d->gate_act;
+  g.C2 = (half_t*)d->C2;
+  g.ldc2 = d->ldc2;
+  g.act2 = d->act2;
   g.lda = d->lda;
   g.ldb = d->ldb;
   g.ldc = d->ldc;
@@ -654,6 +691,11 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   bool f32 = d->out_f32 != 0;
   VN_REQUIRE(!(f32 && d->rowadd), "gemm: rowadd is only supported for f16 output");
+  if (d->gate_src || d->C2) {
+    VN_REQUIRE(!f32 && batch == 1, "gemm: gate/C2 epilogues need f16 output and batch 1");
+    VN_REQUIRE(!d->gate_src || (d->gate_act >= 1 && d->gate_act <= 3 && d->ld_gate % 8 == 0), "gemm: bad gate arguments");
+    VN_REQUIRE(!d->C2 || (d->act2 >= 0 && d->act2 <= 3 && d->ldc2 % 8 == 0), "gemm: bad C2 arguments");
+  }
 
   int cfg = d->tile_hint;
   bool dma = true;

@@ -240,8 +240,8 @@ class TextEngine(Schedule):
             r["w2"], b2 = self._w16(w[p + "mlp.fc2.weight"]), self._w32(w[p + "mlp.fc2.bias"])
             f1 = self._buf((Rt, F))
             a1 = self._buf((Rt, F))
-            f.append(partial(ops.gemm, n2, r["w1"], f1, bias=b1))
-            f.append(partial(ops.act_fwd, f1, a1, act))
+            # fc1 writes the pre-activation (kept for backward) and the activated tensor in one epilogue
+            f.append(partial(ops.gemm, n2, r["w1"], f1, bias=b1, out2=a1, act2=act))
             x_out = self._buf((Rt, D), torch.float32)
             f.append(partial(ops.gemm, a1, r["w2"], x_out, bias=b2, resid=x_mid))
             r.update(qkv=qkv, o=o, lse=lse, x_mid=x_mid, f1=f1)
@@ -282,10 +282,8 @@ class TextEngine(Schedule):
         for r in reversed(self.layers):
             qkv = r["qkv"]
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-            da = self._tmp("cA", Rt, F)
-            bw.append(partial(ops.gemm, g16, r["w2d"], da))
-            df1 = self._tmp("cB", Rt, F)
-            bw.append(partial(ops.act_bwd, da, r["f1"], df1, r["act"]))
+            df1 = self._tmp("cB", Rt, F)   # (dx_out @ W2) * act'(f1): activation backward in the dgrad epilogue
+            bw.append(partial(ops.gemm, g16, r["w2d"], df1, gate=r["f1"], gate_act=r["act"]))
             dn2 = self._tmp("cC", Rt, D)
             bw.append(partial(ops.gemm, df1, r["w1d"], dn2))
             bw.append(partial(self._ln_bwd, r["ln2"], dn2, dxm, dx, g16))     # dx_mid = LN2'(dn2) + dx_out

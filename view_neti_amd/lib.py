@@ -48,6 +48,8 @@ class GemmDesc(C.Structure):
         ("ldx", c_ll),
         ("tile_hint", c_int),
         ("workspace", c_vp), ("workspace_bytes", c_ll), ("split_k", c_int),
+        ("gate_src", c_vp), ("ld_gate", c_ll), ("gate_act", c_int),
+        ("C2", c_vp), ("ldc2", c_ll), ("act2", c_int),
     ]
 
 

@@ -42,7 +42,7 @@ def set_default_gemm_workspace(t):
 
 def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alpha=1.0, act=0,
          tile_hint=0, batch=0, strideA=0, strideB=0, strideC=0, M=None, N=None, K=None, conv=None,
-         lda=None, ldc=None, workspace=None, split_k=0):
+         lda=None, ldc=None, workspace=None, split_k=0, gate=None, gate_act=0, out2=None, act2=0):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  `conv` = dict(mode, Hi, Wi, Ci, Ho, Wo, stride,
     pad_t, pad_l, ups, ldx) turns A into an implicit im2col view of an NHWC image."""
     d = _l.GemmDesc()
@@ -73,6 +73,10 @@ def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alp
     d.act = act
     d.out_f32 = 1 if out.dtype == torch.float32 else 0
     d.tile_hint = tile_hint
+    if gate is not None:  # out *= act'(gate): activation backward fused into the dgrad GEMM
+        d.gate_src, d.ld_gate, d.gate_act = _p(gate), _ld(gate), gate_act
+    if out2 is not None:  # out2 = act2(out)
+        d.C2, d.ldc2, d.act2 = _p(out2), _ld(out2), act2
     ws = workspace if workspace is not None else _default_ws
     if ws is not None:
         d.workspace = ws.data_ptr()
