@@ -102,7 +102,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   constexpr int NT = NWM * NWN * 64;
   constexpr int RSTEP = NT / 8;  // tile rows covered by one pass of all threads
   constexpr int A_IT = BM / RSTEP, B_IT = BN / RSTEP;
-  constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int CS_LD = F32OUT ? (BN + 4) : (BN + 8);  // elements
   constexpr int CS_BYTES = BM * CS_LD * (F32OUT ? 4 : 2);
@@ -270,39 +269,42 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     }
   };
 
-  f32x16 acc[MI][NI];
+  // v_mfma_f32_16x16x32_f16: per flop it moves half the accumulator bytes of the 32x32x16 form and is the more
+  // energy-efficient of the two -- at the 1400 W cap that random operands hit, MFMA-only loops run 13 % faster
+  // with it (tools/lab/overlap_lab.hip) -- so a wave tile is MI16 x NI16 blocks of 16x16 and a 64-wide k-step is
+  // two k32 sub-steps.
+  constexpr int MI16 = WM / 16, NI16 = WN / 16;
+  f32x4 acc[MI16][NI16];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI16; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < NI16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk_total = g.K / 64;
   const int kt_begin = kz * g.kt_per_split;
   const int kt_end = min(nk_total, kt_begin + g.kt_per_split);
 
-  const int frow = lane & 31;
-  const int fhalf = lane >> 5;
-  half8 af[2][MI], bf[2][NI];
+  const int frow = lane & 15;  // row of the 16-row fragment this lane feeds
+  const int fq = lane >> 4;    // its 8-wide k chunk inside the k32 sub-step / the 4-row group of the result it owns
+  half8 af[2][MI16], bf[2][NI16];
   auto load_frags = [&](int buf, int stage, int ks) {
     const char* As = smem + stage * STAGE_BYTES;
     const char* Bs = As + BM * 128;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-      af[buf][i] = as_half8(*reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 32 + frow, ks * 2 + fhalf)));
+    for (int i = 0; i < MI16; ++i)
+      af[buf][i] = as_half8(*reinterpret_cast<const u32x4*>(As + lds_off(wm0 + i * 16 + frow, ks * 4 + fq)));
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      bf[buf][j] = as_half8(*reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 32 + frow, ks * 2 + fhalf)));
+    for (int j = 0; j < NI16; ++j)
+      bf[buf][j] = as_half8(*reinterpret_cast<const u32x4*>(Bs + lds_off(wn0 + j * 16 + frow, ks * 4 + fq)));
   };
   auto mma = [&](int buf) {
     if constexpr (NT == 256) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI16; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI16; ++j)
         // operands swapped: D[row = n][col = m]  => each lane owns 4 consecutive n of one m
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
     if constexpr (NT == 256) __builtin_amdgcn_s_setprio(0);
   };
 
@@ -327,10 +329,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       if (kt + 2 < kt_end) issue(kt + 2, st_new, false);
       load_frags(1, st, 1);
       mma(0);
-      load_frags(0, st, 2);
-      mma(1);
-      load_frags(1, st, 3);
-      mma(0);
       if (kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -354,10 +352,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       load_frags(0, cur, 0);
       load_frags(1, cur, 1);
       mma(0);
-      load_frags(0, cur, 2);
-      mma(1);
-      load_frags(1, cur, 3);
-      mma(0);
       mma(1);
       if (kt + 1 < kt_end) store_lds(cur ^ 1);
       if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -369,21 +363,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   if (g.ksplit > 1) {
     float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI16; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int m = m0 + wm0 + i * 32 + frow;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn0 + j * 32 + 8 * q + 4 * fhalf;
-          if (m < g.M && n < g.N) {
-            float* p = ws + (long long)m * g.N + n;
-            if (n + 4 <= g.N && (g.N & 3) == 0) {
-              f32x4 o = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-              *reinterpret_cast<f32x4*>(p) = o;
-            } else {
-              for (int e = 0; e < 4 && n + e < g.N; ++e) p[e] = acc[i][j][4 * q + e];
-            }
+      for (int j = 0; j < NI16; ++j) {
+        const int m = m0 + wm0 + i * 16 + frow;
+        const int n = n0 + wn0 + j * 16 + 4 * fq;
+        if (m < g.M && n < g.N) {
+          float* p = ws + (long long)m * g.N + n;
+          if (n + 4 <= g.N && (g.N & 3) == 0) {
+            *reinterpret_cast<f32x4*>(p) = acc[i][j];
+          } else {
+            for (int e = 0; e < 4 && n + e < g.N; ++e) p[e] = acc[i][j][e];
           }
         }
       }
@@ -393,28 +383,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ---------
   // (the trailing __syncthreads of the K loop guarantees nobody still reads the stages)
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+  for (int i = 0; i < MI16; ++i) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int ml = wm0 + i * 32 + frow;
+    for (int j = 0; j < NI16; ++j) {
+      const int ml = wm0 + i * 16 + frow;
+      const int nl = wn0 + j * 16 + 4 * fq;
+      float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nl = wn0 + j * 32 + 8 * q + 4 * fhalf;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = acc[i][j][4 * q + e] * g.alpha;
-          int n = n0 + nl + e;
-          if (g.bias != nullptr && n < g.N) x += g.bias[n];
-          v[e] = apply_act(x, g.act);
-        }
-        if constexpr (F32OUT) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(smem + ((size_t)ml * CS_LD + nl) * 4) = o;
-        } else {
-          half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *reinterpret_cast<half4*>(smem + ((size_t)ml * CS_LD + nl) * 2) = o;
-        }
+      for (int e = 0; e < 4; ++e) {
+        float x = acc[i][j][e] * g.alpha;
+        int n = n0 + nl + e;
+        if (g.bias != nullptr && n < g.N) x += g.bias[n];
+        v[e] = apply_act(x, g.act);
+      }
+      if constexpr (F32OUT) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(smem + ((size_t)ml * CS_LD + nl) * 4) = o;
+      } else {
+        half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4*>(smem + ((size_t)ml * CS_LD + nl) * 2) = o;
       }
     }
   }
