@@ -89,11 +89,20 @@ typedef struct vneti_gemm_desc {
   void* C2;
   long long ldc2;
   int act2;
+  /* GroupNorm statistics of the f16 output fused into the epilogue (split_k must be 1): the rows are images
+     of gn_hw pixels, the N columns gn_groups groups of gn_cpg channels; every tile adds its (sum, sum of
+     squares) per (image, group) to gn_sums[image][tile_m % gn_slots][group][2] with atomics.  The caller
+     zeroes gn_sums; vneti_groupnorm_fwd_sums consumes it (the statistics pass of ResnetBlock2D.norm2 etc.
+     without re-reading the tensor). */
+  float* gn_sums;
+  int gn_hw, gn_cpg, gn_groups, gn_slots;
 } vneti_gemm_desc;
 
 int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream);
 /* the tile configuration (1..4, see tile_hint) the heuristic picks for a problem size */
 int vneti_gemm_select_tile(int M, int N, int batch);
+/* the split-K factor split_k = 0 resolves to for a problem, tile configuration and workspace size (1 = no split) */
+int vneti_gemm_select_split(int M, int N, int K, int batch, int tile_hint, long long workspace_bytes);
 
 /* 3x3 im2col for convolutions with tiny Cin (conv_in of UNet / VAE, dgrad of conv_out):
  * out[m][tap*C + c] (f16, row length 64, zero padded) from an arbitrarily strided image.
@@ -129,6 +138,12 @@ long long vneti_groupnorm_ws_floats(int Bn, int HW, int C, int G);
 int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
                         const float* beta, float* mean, float* rstd, float* ws, int Bn, int HW,
                         int C, int G, float eps, int silu, void* stream);
+/* GroupNorm(+SiLU) forward whose statistics pass already ran inside the GEMM that produced x
+   (vneti_gemm_desc.gn_sums, `slots` slots per sample): one launch that finishes mean / rstd from the sums,
+   normalises, and publishes mean / rstd for the backward. */
+int vneti_groupnorm_fwd_sums(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                             const float* beta, const float* sums, int slots, float* mean, float* rstd,
+                             int Bn, int HW, int C, int G, float eps, int silu, void* stream);
 /* dx = d(loss)/d(x) given dy = d(loss)/d(y); y = silu?(GN(x)).  If dx_accum != NULL it is
  * added (f16, row stride lddx) — used where two gradient paths meet. */
 int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x, long long ldx,

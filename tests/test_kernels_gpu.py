@@ -147,6 +147,45 @@ def test_gemm_gate_and_second_output(act, split, N):
     check(f"gemm out2 act{act} split{split}", out2, fn(out.float().cpu()), 1e-3)
 
 
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9])
+@pytest.mark.parametrize("Bn,HW,C", [(4, 64, 320), (2, 256, 128), (3, 576, 640), (2, 4096, 32 * 4)])
+def test_gemm_groupnorm_sums_and_fused_apply(hint, Bn, HW, C):
+    """GroupNorm statistics accumulated by the GEMM epilogue (rows = Bn images of HW pixels, 32 groups) and the
+    one-launch GroupNorm that consumes them, against torch.nn.functional.group_norm of the SAME f16 tensor
+    (ResnetBlock2D.norm1/norm2 + SiLU, diffusers resnet.py)."""
+    ops = _ops()
+    G, S, K = 32, 8, 128
+    M = Bn * HW
+    A = rnd(M, K, seed=61)
+    B = rnd(C, K, scale=1.0 / math.sqrt(K), seed=62)
+    bias = rnd(C, seed=63, dtype=torch.float32) * 2
+    res = rnd(M, C, seed=64)
+    out = torch.zeros(M, C + 8, dtype=torch.float16, device=DEV)[:, :C]
+    sums = torch.zeros(Bn, S, G, 2, dtype=torch.float32, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), tile_hint=hint, split_k=1,
+             gn_sums=sums, gn_hw=HW, gn_groups=G, gn_slots=S)
+    torch.cuda.synchronize()
+    x = out.float().cpu().reshape(Bn, HW, G, C // G)
+    ref_s = x.sum((1, 3))
+    ref_q = (x * x).sum((1, 3))
+    got = sums.cpu().sum(1)
+    check(f"gn sums hint{hint}", got[..., 0], ref_s, 1e-3)
+    check(f"gn sumsq hint{hint}", got[..., 1], ref_q, 1e-5)
+    gamma = rnd(C, seed=65, dtype=torch.float32) * 0.1 + 1
+    beta = rnd(C, seed=66, dtype=torch.float32) * 0.1
+    y = torch.zeros(M, C, dtype=torch.float16, device=DEV)
+    mean = torch.zeros(Bn * G, dtype=torch.float32, device=DEV)
+    rstd = torch.zeros(Bn * G, dtype=torch.float32, device=DEV)
+    ops.groupnorm_fwd_sums(out, y, gamma.to(DEV), beta.to(DEV), sums, S, mean, rstd, Bn, HW, C, G, 1e-5, True)
+    torch.cuda.synchronize()
+    xn = out.float().cpu().reshape(Bn, HW, C).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xn, G, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(M, C)
+    check(f"gn fused apply hint{hint}", y, ref, 2e-3)
+    xg = xn.reshape(Bn, G, -1)
+    check("gn mean", mean.cpu().reshape(Bn, G), xg.mean(-1), 1e-4)
+    check("gn rstd", rstd.cpu().reshape(Bn, G), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-4)
+
+
 # ------------------------------------------------------------------------------------------ conv
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()

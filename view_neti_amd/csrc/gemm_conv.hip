@@ -42,6 +42,8 @@ struct GemmArgs {
   half_t* C2;
   long long ld_gate, ldc2;
   int gate_act, act2;
+  float* gn_sums;  // [image][slot][G][2] running (sum, sum of squares) of the f16 output, see vneti_gemm_desc
+  int gn_hw, gn_cpg, gn_G, gn_slots;
   long long lda, ldb, ldc, ld_rowadd, ldr;
   long long strideA, strideB, strideC;
   uint32_t a_bytes, b_bytes;
@@ -106,7 +108,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   constexpr int CS_LD = F32OUT ? (BN + 4) : (BN + 8);  // elements
   constexpr int CS_BYTES = BM * CS_LD * (F32OUT ? 4 : 2);
   constexpr int LDS_BYTES = (NSTG * STAGE_BYTES > CS_BYTES) ? NSTG * STAGE_BYTES : CS_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  // GroupNorm statistics of the output tile (f16 epilogue only): [GN_IMG images][GN_NG groups][2] floats
+  constexpr int GN_IMG = 5, GN_NG = BN / 4 + 2;
+  constexpr int GN_BYTES = F32OUT ? 0 : GN_IMG * GN_NG * 2 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + GN_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -380,6 +385,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     return;
   }
 
+  if constexpr (!F32OUT) {
+    if (g.gn_sums) {
+      float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
+      for (int i = tid; i < GN_IMG * GN_NG * 2; i += NT) gacc[i] = 0.f;
+    }
+  }
   // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ---------
   // (the trailing __syncthreads of the K loop guarantees nobody still reads the stages)
 #pragma unroll
@@ -437,10 +448,54 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     const half_t* Rb = reinterpret_cast<const half_t*>(g.resid);
     if (Rb) Rb += (long long)bz * g.strideC;
     constexpr int CPR = BN / 8;
-    for (int idx = tid; idx < BM * CPR; idx += NT) {
+    static_assert(NT % CPR == 0 && CPR <= 32 && (BM * CPR) % NT == 0, "a thread keeps one 8-column chunk over all its rows");
+    // GroupNorm statistics of what this tile stores: a thread's chunk touches at most two groups (lo/hi, like
+    // csrc/norms.hip); its running sums go to the LDS accumulators whenever the image changes and at the end
+    float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
+    const bool gn = g.gn_sums != nullptr;
+    const int gn_img0 = gn ? m0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
+    const int gn_c = n0 + (tid % CPR) * 8;
+    const int gn_glo = gn ? gn_c / g.gn_cpg : 0;
+    const int gn_split = gn ? (gn_glo + 1) * g.gn_cpg - gn_c : 8;  // columns [0, split) of the chunk are in group lo
+    int gn_img = -1;
+    float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
+    // flush = wave-uniform: the lanes that share a chunk column (lane % CPR) are summed with cross-lane moves first, so a
+    // wave issues CPR x 4 LDS atomics on mostly distinct addresses instead of 256 colliding ones
+    auto gn_flush = [&]() {
+      const int iref = __builtin_amdgcn_readfirstlane(gn_img);
+      const bool uni = __all(gn_img == iref) && iref >= 0;
+      if (uni) {
+#pragma unroll
+        for (int off = 32; off >= CPR; off >>= 1) {
+          s_lo += __shfl_xor(s_lo, off);
+          q_lo += __shfl_xor(q_lo, off);
+          s_hi += __shfl_xor(s_hi, off);
+          q_hi += __shfl_xor(q_hi, off);
+        }
+      }
+      if (gn_img >= 0 && (!uni || lane < CPR)) {
+        float* a = gacc + ((gn_img - gn_img0) * GN_NG + (gn_glo - gn_g0t)) * 2;
+        atomicAdd(a, s_lo);
+        atomicAdd(a + 1, q_lo);
+        if (gn_split < 8) {
+          atomicAdd(a + 2, s_hi);
+          atomicAdd(a + 3, q_hi);
+        }
+      }
+      s_lo = q_lo = s_hi = q_hi = 0.f;
+    };
+    for (int idx = tid; idx < BM * CPR; idx += NT) {  // BM * CPR is a multiple of NT: uniform trip count
       int r = idx / CPR, c = (idx - r * CPR) * 8;
       int m = m0 + r, n = n0 + c;
-      if (m >= g.M || n >= g.N) continue;
+      const bool valid = m < g.M && n < g.N;
+      if (gn) {
+        const int img = valid ? m / g.gn_hw : gn_img;
+        if (__any(img != gn_img)) {
+          gn_flush();
+          gn_img = img;
+        }
+      }
+      if (!valid) continue;
       half8 v = as_half8(*reinterpret_cast<const u32x4*>(smem + ((size_t)r * CS_LD + c) * 2));
       const half_t* radd = g.rowadd ? g.rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + n : nullptr;
       if (n + 8 <= g.N) {
@@ -460,6 +515,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)pre[e], g.gate_act));
         }
         *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
+        if (gn) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = (float)v[e];
+            if (e < gn_split) {
+              s_lo += x;
+              q_lo += x * x;
+            } else {
+              s_hi += x;
+              q_hi += x * x;
+            }
+          }
+        }
         if (g.C2) {
           half8 o2;
 #pragma unroll
@@ -474,7 +542,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
           if (g.gate_src) x = (float)(half_t)(x * act_grad((float)g.gate_src[(long long)m * g.ld_gate + n + e], g.gate_act));
           Cb[(long long)m * g.ldc + n + e] = (half_t)x;
           if (g.C2) g.C2[(long long)m * g.ldc2 + n + e] = (half_t)apply_act((float)(half_t)x, g.act2);
+          if (gn) {
+            const float xs = (float)(half_t)x;
+            if (e < gn_split) {
+              s_lo += xs;
+              q_lo += xs * xs;
+            } else {
+              s_hi += xs;
+              q_hi += xs * xs;
+            }
+          }
         }
+      }
+    }
+    if (gn) {
+      gn_flush();
+      __syncthreads();
+      const int slot = tile_m % g.gn_slots;
+      for (int i = tid; i < GN_IMG * GN_NG; i += NT) {
+        const float sv = gacc[2 * i], qv = gacc[2 * i + 1];
+        if (sv == 0.f && qv == 0.f) continue;
+        const int img = gn_img0 + i / GN_NG, grp = gn_g0t + i % GN_NG;
+        float* dst = g.gn_sums + (((long long)img * g.gn_slots + slot) * g.gn_G + grp) * 2;
+        unsafeAtomicAdd(dst, sv);  // hardware global_atomic_add_f32
+        unsafeAtomicAdd(dst + 1, qv);
       }
     }
   }
@@ -604,6 +695,18 @@ int select_ksplit(int M, int N, int K, int batch, int tile, long long ws_floats)
 
 extern "C" int vneti_gemm_select_tile(int M, int N, int batch) { return select_tile(M, N, batch > 0 ? batch : 1); }
 
+extern "C" int vneti_gemm_select_split(int M, int N, int K, int batch, int tile_hint, long long workspace_bytes) {
+  if (batch <= 0) batch = 1;
+  int cfg = tile_hint >= 100 ? tile_hint - 100 : tile_hint;
+  if (cfg == 0) cfg = select_tile(M, N, batch);
+  if (cfg < 1 || cfg > 9 || K % 64 != 0) return -1;
+  int ks = select_ksplit(M, N, K, batch, cfg, workspace_bytes / 4);
+  const int nk = K / 64;
+  if (ks > nk) ks = nk;
+  if (ks < 1) ks = 1;
+  return cdiv(nk, cdiv(nk, ks));
+}
+
 extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   VN_REQUIRE(d != nullptr, "gemm: null descriptor");
   VN_REQUIRE(d->A && d->B && d->C, "gemm: null operand pointer");
@@ -625,6 +728,11 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   g.C2 = (half_t*)d->C2;
   g.ldc2 = d->ldc2;
   g.act2 = d->act2;
+  g.gn_sums = d->gn_sums;
+  g.gn_hw = d->gn_hw;
+  g.gn_cpg = d->gn_cpg;
+  g.gn_G = d->gn_groups;
+  g.gn_slots = d->gn_slots;
   g.lda = d->lda;
   g.ldb = d->ldb;
   g.ldc = d->ldc;
@@ -682,6 +790,14 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     VN_REQUIRE(!f32 && batch == 1, "gemm: gate/C2 epilogues need f16 output and batch 1");
     VN_REQUIRE(!d->gate_src || (d->gate_act >= 1 && d->gate_act <= 3 && d->ld_gate % 8 == 0), "gemm: bad gate arguments");
     VN_REQUIRE(!d->C2 || (d->act2 >= 0 && d->act2 <= 3 && d->ldc2 % 8 == 0), "gemm: bad C2 arguments");
+  }
+
+  if (d->gn_sums) {
+    VN_REQUIRE(!f32 && batch == 1, "gemm: gn_sums needs f16 output and batch 1");
+    VN_REQUIRE(d->gn_hw >= 64 && d->gn_cpg >= 4 && d->gn_groups > 0 && d->gn_slots > 0 && d->N == d->gn_cpg * d->gn_groups &&
+                   d->M % d->gn_hw == 0 && (d->gn_cpg >= 8 || d->gn_cpg == 4),
+               "gemm: bad gn_sums geometry hw=%d cpg=%d G=%d", d->gn_hw, d->gn_cpg, d->gn_groups);
+    VN_REQUIRE(d->split_k == 1, "gemm: gn_sums needs split_k = 1 (the statistics live in the fused epilogue)");
   }
 
   int cfg = d->tile_hint;

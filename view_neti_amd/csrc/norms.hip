@@ -161,7 +161,24 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GNGeom g, const float*
   }
 }
 
-template <bool BWD, bool SILU>
+// mean / rstd of one (sample, group) from the (sum, sum of squares) slots a GEMM epilogue accumulated
+__device__ __forceinline__ void gn_stat_from_sums(const GNGeom& g, const float* sums, int slots, int b, int gi, float eps,
+                                                  float& m, float& r) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int sl = 0; sl < slots; ++sl) {
+    const float* p = sums + (((long long)b * slots + sl) * g.G + gi) * 2;
+    s0 += (double)p[0];
+    s1 += (double)p[1];
+  }
+  const double n = (double)g.HW * g.cpg;
+  const double mu = s0 / n;
+  double var = s1 / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  m = (float)mu;
+  r = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <bool BWD, bool SILU, bool FROM_SUMS = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* __restrict__ x, long long ldx,
                                                        const half_t* __restrict__ dy, long long lddy,
                                                        const float* __restrict__ gamma,
@@ -170,7 +187,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
                                                        const float* __restrict__ rstd,
                                                        const float* __restrict__ c1, const float* __restrict__ c2,
                                                        half_t* __restrict__ out, long long ldo,
-                                                       const half_t* __restrict__ accum, long long ldacc) {
+                                                       const half_t* __restrict__ accum, long long ldacc,
+                                                       const float* __restrict__ sums = nullptr, int slots = 0,
+                                                       float eps = 0.f, float* __restrict__ mean_out = nullptr,
+                                                       float* __restrict__ rstd_out = nullptr) {
   const int slab = blockIdx.x, b = blockIdx.y;
   int tx, ty;
   bool active;
@@ -191,8 +211,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
       ga[j] = gamma[ch0 + j];
       be[j] = beta[ch0 + j];
     }
-    const float mlo = mean[b * g.G + g0], rlo = rstd[b * g.G + g0];
-    const float mhi = mean[b * g.G + g1], rhi = rstd[b * g.G + g1];
+    float mlo, rlo, mhi, rhi;
+    if constexpr (FROM_SUMS) {
+      // the statistics pass ran inside the producing GEMM: finish it here (every thread for its two groups;
+      // slab 0 also publishes mean / rstd for the backward)
+      gn_stat_from_sums(g, sums, slots, b, g0, eps, mlo, rlo);
+      mhi = mlo;
+      rhi = rlo;
+      if (g1 != g0) gn_stat_from_sums(g, sums, slots, b, g1, eps, mhi, rhi);
+      if (slab == 0 && ty == 0) {
+        mean_out[b * g.G + g0] = mlo;
+        rstd_out[b * g.G + g0] = rlo;
+        mean_out[b * g.G + g1] = mhi;
+        rstd_out[b * g.G + g1] = rhi;
+      }
+    } else {
+      mlo = mean[b * g.G + g0];
+      rlo = rstd[b * g.G + g0];
+      mhi = mean[b * g.G + g1];
+      rhi = rstd[b * g.G + g1];
+    }
     float c1lo = 0.f, c2lo = 0.f, c1hi = 0.f, c2hi = 0.f;
     if (BWD) {
       c1lo = c1[b * g.G + g0];
@@ -492,6 +530,28 @@ extern "C" int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long l
                        (const half_t*)nullptr, 0LL, gamma, beta, (const float*)mean, (const float*)rstd,
                        (const float*)nullptr, (const float*)nullptr, (half_t*)y, ldy, (const half_t*)nullptr, 0LL);
   return vneti_check_launch("groupnorm_fwd");
+}
+
+extern "C" int vneti_groupnorm_fwd_sums(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                                        const float* beta, const float* sums, int slots, float* mean, float* rstd,
+                                        int Bn, int HW, int C, int G, float eps, int silu, void* stream) {
+  GNGeom g;
+  VN_REQUIRE(gn_geom(g, Bn, HW, C, G) == 0, "groupnorm: unsupported shape B=%d HW=%d C=%d G=%d", Bn, HW, C, G);
+  VN_REQUIRE(x && y && gamma && beta && sums && mean && rstd && slots > 0, "groupnorm_fwd_sums: null pointer");
+  VN_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "groupnorm_fwd_sums: ld % 8 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(g.nslab, Bn);
+  if (silu)
+    hipLaunchKernelGGL((gn_apply_kernel<false, true, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                       (const half_t*)nullptr, 0LL, gamma, beta, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (half_t*)y, ldy, (const half_t*)nullptr, 0LL,
+                       sums, slots, eps, mean, rstd);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<false, false, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                       (const half_t*)nullptr, 0LL, gamma, beta, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (half_t*)y, ldy, (const half_t*)nullptr, 0LL,
+                       sums, slots, eps, mean, rstd);
+  return vneti_check_launch("groupnorm_fwd_sums");
 }
 
 extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x, long long ldx,

@@ -20,7 +20,7 @@ class T:
     """Activation handle: forward view `v`, gradient view `g`, and whether `g` already holds a
     contribution (tracked in backward *execution* order while the schedule is built)."""
 
-    __slots__ = ("v", "g", "gw", "rows", "cols", "children", "need_grad")
+    __slots__ = ("v", "g", "gw", "rows", "cols", "children", "need_grad", "producer")
 
     def __init__(self, v, g=None, need_grad=True):
         self.v = v
@@ -29,6 +29,7 @@ class T:
         self.rows, self.cols = v.shape
         self.children: List["T"] = []
         self.need_grad = need_grad
+        self.producer = None  # index in Schedule.fwd of the single GEMM that writes all of `v` (see _produced)
 
 
 def rup(x, m):
@@ -57,6 +58,8 @@ class Schedule:
         self.ws = self._buf((16 * 2 ** 20,), torch.float32)
         self.ws_side = None
         self._side_stream = None
+        self._gn_fusable: List[dict] = []
+        self.gn_sums = None
         if ops._default_ws is None or ops._default_ws.device != torch.device(device, torch.cuda.current_device()):
             ops.set_default_gemm_workspace(torch.empty(16 * 2 ** 20, dtype=torch.float32, device=device))
 
@@ -190,6 +193,59 @@ class Schedule:
             self.ws_side = self._buf((4 * 2 ** 20,), torch.float32)
         return launch
 
+    # ------------------------------------------------------------------ GroupNorm statistics in the producer
+    GN_SLOTS = 8
+
+    def _produced(self, t: T):
+        """the launch just appended to `fwd` is the one GEMM that writes every element of t.v"""
+        t.producer = len(self.fwd) - 1
+        return t
+
+    def fuse_gn_stats(self):
+        """After autotuning: wherever a GroupNorm input comes out of one GEMM that runs without split-K, that GEMM's
+        epilogue accumulates the per-(sample, group) sums (vneti_gemm_desc.gn_sums) and the GroupNorm becomes ONE
+        launch (vneti_groupnorm_fwd_sums) instead of statistics + finalize + apply: one read of the tensor and two
+        launches less per layer.  One memset at the head of the list clears all the sums of the schedule."""
+        import os
+        if os.environ.get("VNETI_NO_GN_FUSE"):
+            return 0
+        S, G, B = self.GN_SLOTS, self.groups, self.B
+        todo = []
+        for rec in self._gn_fusable:
+            f = self.fwd[rec["prod"]]
+            kw = f.keywords
+            hw, Cc = rec["hw"], rec["C"]
+            cpg = Cc // G
+            # split-K launches keep the standalone statistics pass (their epilogue runs in the reduce kernel);
+            # an un-tuned launch (split_k not pinned) is pinned to 1 here
+            if getattr(f, "func", None) is not ops.gemm or kw.get("batch"):
+                continue
+            if kw.get("split_k") != 1:  # 0 / unset = the library heuristic: ask what it resolves to
+                M_, N_, K_ = self._gemm_key(f)[:3]
+                ws = kw.get("workspace")
+                wsb = ws.numel() * ws.element_size() if ws is not None else 0
+                if ops.gemm_select_split(M_, N_, K_, 1, kw.get("tile_hint") or 0, wsb) != 1:
+                    continue
+            if hw < 64 or not (cpg >= 8 or cpg == 4) or kw.get("gn_sums") is not None:
+                continue
+            todo.append(rec)
+        if not todo:
+            return 0
+        self.gn_sums = self._buf((len(todo), B, S, G, 2), torch.float32, zero=True)
+        for i, rec in enumerate(todo):
+            sums = self.gn_sums[i]
+            f = self.fwd[rec["prod"]]
+            kw = dict(f.keywords)
+            kw.update(gn_sums=sums, gn_hw=rec["hw"], gn_groups=G, gn_slots=S, split_k=1)
+            self.fwd[rec["prod"]] = self._rebound(f, ops.gemm, kw)
+            g = rec["gn"]
+            self.fwd[rec["idx"]] = partial(ops.groupnorm_fwd_sums, rec["x"], rec["y"], g["gamma"], g["beta"], sums, S,
+                                           g["mean"], g["rstd"], B, rec["hw"], rec["C"], G, rec["eps"], rec["silu"])
+        arena = self.gn_sums
+        self.fwd.insert(0, arena.zero_)
+        self._gn_fusable = []
+        return len(todo)
+
     # ------------------------------------------------------------------ layer builders
     def _gn(self, x: T, name, w, eps, silu):
         Cc = x.cols
@@ -200,6 +256,9 @@ class Schedule:
         y = self._buf((x.rows, Cc))
         self.fwd.append(partial(ops.groupnorm_fwd, x.v, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"],
                                 self.gn_ws, self.B, hw, Cc, self.groups, eps, silu))
+        if x.producer is not None:
+            self._gn_fusable.append(dict(idx=len(self.fwd) - 1, prod=x.producer, gn=rec, x=x.v, y=y, hw=hw, C=Cc,
+                                         eps=eps, silu=silu))
         return y, rec
 
     def _gn_bwd_fn(self, rec, dy):
@@ -225,6 +284,7 @@ class Schedule:
         h1 = T(self._buf((M, cout)))
         self.fwd.append(partial(ops.gemm, n1, w1, h1.v, bias=b1, rowadd=radd, rows_per_group=h * wd, M=M,
                                 conv=self._conv_desc(h, wd, cin, h, wd, 1, 1, 0, cin)))
+        self._produced(h1)
         n2, gn2 = self._gn(h1, name + "norm2", w, self.eps, True)
         w2 = self._w16(packing.conv3x3_fwd(w[name + "conv2.weight"]))
         b2 = self._w32(w[name + "conv2.bias"])
@@ -240,6 +300,7 @@ class Schedule:
             resid = x.v
         self.fwd.append(partial(ops.gemm, n2, w2, out.v, bias=b2, resid=resid, M=M,
                                 conv=self._conv_desc(h, wd, cout, h, wd, 1, 1, 0, cout)))
+        self._produced(out)
         rec = dict(kind="resnet", x=x, out=out, h1=h1, gn1=gn1, gn2=gn2, cin=cin, cout=cout, h=h, wd=wd,
                    need_dx=need_dx, name=name)
         if self.need_backward and need_dx:
@@ -290,6 +351,7 @@ class Schedule:
         out = T(out_view if out_view is not None else self._buf((M, Cc)))
         self.fwd.append(partial(ops.gemm, x.v, wf, out.v, bias=b, M=M,
                                 conv=self._conv_desc(h, wd, Cc, h // 2, wd // 2, 2, pad, 0, x.v.stride(0))))
+        self._produced(out)
         rec = dict(kind="down", x=x, out=out, C=Cc, h=h, wd=wd, pad=pad)
         if self.need_backward:
             rec["wd_"] = self._w16(packing.conv3x3_dgrad(w[name + "weight"]))

@@ -30,7 +30,8 @@ from .schedule import Schedule, T, rup as _rup
 
 class UNetEngine(Schedule):
     def __init__(self, cfg: sc.UNetConfig, weights: Dict[str, torch.Tensor], batch: int, height: int, width: int,
-                 ctx_len: int = 77, device: str = "cuda", need_backward: bool = True, autotune: bool = True):
+                 ctx_len: int = 77, device: str = "cuda", need_backward: bool = True, autotune: bool = True,
+                 fuse_gn: bool = True):
         super().__init__(batch, cfg.norm_num_groups, cfg.norm_eps, device, need_backward)
         self.cfg = cfg
         self.H, self.W = height, width
@@ -53,6 +54,8 @@ class UNetEngine(Schedule):
         if autotune:
             self.autotune()
         self.bind_workspace()
+        if fuse_gn:
+            self.fuse_gn_stats()
 
     # ------------------------------------------------------------------ time embedding
     def _pack_time_weights(self, w):
@@ -145,6 +148,7 @@ class UNetEngine(Schedule):
         r["w_out"], b_out = self._w16(w[name + "proj_out.weight"].reshape(Cc, Cc)), self._w32(w[name + "proj_out.bias"])
         out = T(out_view if out_view is not None else self._buf((M, Cc)))
         self.fwd.append(partial(ops.gemm, h3, r["w_out"], out.v, bias=b_out, resid=x.v))
+        self._produced(out)
         r.update(out=out, h0=h0, h1=h1, h2=h2, qkv=qkv, o1=o1, lse1=lse1, q2=q2, k2=k2, v2=v2, o2=o2, lse2=lse2,
                  p=p)
         if self.need_backward:
@@ -230,6 +234,7 @@ class UNetEngine(Schedule):
         out = T(out_view if out_view is not None else self._buf((M, Cc)))
         self.fwd.append(partial(ops.gemm, x.v, wf, out.v, bias=b, M=M,
                                 conv=self._conv_desc(h, wd, Cc, 2 * h, 2 * wd, 1, 1, 1, x.v.stride(0))))
+        self._produced(out)
         rec = dict(kind="up", x=x, out=out, C=Cc, h=h, wd=wd)
         if self.need_backward:
             rec["wd_"] = self._w16(packing.conv3x3_dgrad(w[name + "weight"]))
@@ -299,7 +304,7 @@ class UNetEngine(Schedule):
         self.fwd.append(partial(ops.im2col3x3_small, self.x_in, col, B, cfg.in_channels, H, W, H, W, 1, 1, 1,
                                 self.x_in.stride()))
         self.fwd.append(partial(ops.gemm, col, w_in, sv, bias=b_in))
-        hcur = adopt(T(sv, need_grad=False), key, "skip")
+        hcur = adopt(self._produced(T(sv, need_grad=False)), key, "skip")
         layer = 0
         first = True  # nothing upstream of the first cross-attention needs a gradient
         cin = boc[0]

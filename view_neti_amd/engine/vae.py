@@ -39,6 +39,7 @@ class VAEEncoderEngine(Schedule):
         if autotune:
             self.autotune()
         self.bind_workspace()
+        self.fuse_gn_stats()
 
     def _build(self, w):
         cfg = self.cfg
@@ -52,7 +53,7 @@ class VAEEncoderEngine(Schedule):
         self.fwd.append(partial(ops.im2col3x3_small, self.x_in, col, B, cfg.in_channels, H, W, H, W, 1, 1, 1,
                                 self.x_in.stride()))
         self.fwd.append(partial(ops.gemm, col, w_in, h0, bias=b_in))
-        hcur = T(h0, need_grad=False)
+        hcur = self._produced(T(h0, need_grad=False))
         cin = boc[0]
         h, wd = H, W
         for i, cout in enumerate(boc):
@@ -104,7 +105,7 @@ class VAEEncoderEngine(Schedule):
         bo = self._w32(w[name + "proj_attn.bias"])
         out = T(self._buf((M, Cc)), need_grad=False)
         self.fwd.append(partial(ops.gemm, o, wo, out.v, bias=bo, resid=x.v))
-        return out
+        return self._produced(out)
 
 
 class VAEDecoderEngine(VAEEncoderEngine):
@@ -128,6 +129,7 @@ class VAEDecoderEngine(VAEEncoderEngine):
         if autotune:
             self.autotune()
         self.bind_workspace()
+        self.fuse_gn_stats()
 
     def _build_decoder(self, w):
         cfg = self.cfg
@@ -147,7 +149,7 @@ class VAEDecoderEngine(VAEEncoderEngine):
         h0 = self._buf((M, cm))
         f.append(partial(ops.im2col3x3_small, zq, col, B, lc, h, wd, h, wd, 1, 1, 1, zq.stride()))
         f.append(partial(ops.gemm, col, w_in, h0, bias=b_in))
-        cur = T(h0, need_grad=False)
+        cur = self._produced(T(h0, need_grad=False))
         cur = self._resnet(cur, cm, cm, "decoder.mid_block.resnets.0.", w, None, h, wd, need_dx=False)
         cur = self._mid_attention(cur, cm, "decoder.mid_block.attentions.0.", w, h * wd)
         cur = self._resnet(cur, cm, cm, "decoder.mid_block.resnets.1.", w, None, h, wd, need_dx=False)
@@ -163,7 +165,7 @@ class VAEDecoderEngine(VAEEncoderEngine):
                 up = T(self._buf((4 * cur.rows, cout)), need_grad=False)
                 f.append(partial(ops.gemm, cur.v, wu, up.v, bias=bu, M=4 * cur.rows,
                                  conv=self._conv_desc(h, wd, cout, 2 * h, 2 * wd, 1, 1, 1, cur.v.stride(0))))
-                cur = up
+                cur = self._produced(up)
                 h, wd = 2 * h, 2 * wd
             cin = cout
         n, _ = self._gn(cur, "decoder.conv_norm_out", w, cfg.norm_eps, True)

@@ -50,6 +50,7 @@ class GemmDesc(C.Structure):
         ("workspace", c_vp), ("workspace_bytes", c_ll), ("split_k", c_int),
         ("gate_src", c_vp), ("ld_gate", c_ll), ("gate_act", c_int),
         ("C2", c_vp), ("ldc2", c_ll), ("act2", c_int),
+        ("gn_sums", c_vp), ("gn_hw", c_int), ("gn_cpg", c_int), ("gn_groups", c_int), ("gn_slots", c_int),
     ]
 
 
@@ -119,6 +120,8 @@ SIGNATURES = {
     "im2col3x3_small": [c_vp, c_int, c_ll, c_ll, c_ll, c_ll, c_vp] + [c_int] * 9 + [c_vp],
     "transpose_f16": [c_vp, c_ll, c_ll, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
     "transpose_f16_multi": [c_vp, c_int, c_vp],
+    "groupnorm_fwd_sums": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                           c_f, c_int, c_vp],
     "groupnorm_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                       c_f, c_int, c_vp],
     "groupnorm_bwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp,
@@ -169,7 +172,7 @@ SIGNATURES = {
     "mapper_inputs": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp],
 }
 
-INT_FUNCS = {"gemm_select_tile": [c_int] * 3}
+INT_FUNCS = {"gemm_select_tile": [c_int] * 3, "gemm_select_split": [c_int] * 5 + [c_ll]}
 
 LL_FUNCS = {
     "mapper_num_params": [c_int] * 4,

@@ -42,7 +42,8 @@ def set_default_gemm_workspace(t):
 
 def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alpha=1.0, act=0,
          tile_hint=0, batch=0, strideA=0, strideB=0, strideC=0, M=None, N=None, K=None, conv=None,
-         lda=None, ldc=None, workspace=None, split_k=0, gate=None, gate_act=0, out2=None, act2=0):
+         lda=None, ldc=None, workspace=None, split_k=0, gate=None, gate_act=0, out2=None, act2=0,
+         gn_sums=None, gn_hw=0, gn_groups=0, gn_slots=0):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  `conv` = dict(mode, Hi, Wi, Ci, Ho, Wo, stride,
     pad_t, pad_l, ups, ldx) turns A into an implicit im2col view of an NHWC image."""
     d = _l.GemmDesc()
@@ -77,6 +78,9 @@ def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alp
         d.gate_src, d.ld_gate, d.gate_act = _p(gate), _ld(gate), gate_act
     if out2 is not None:  # out2 = act2(out)
         d.C2, d.ldc2, d.act2 = _p(out2), _ld(out2), act2
+    if gn_sums is not None:  # GroupNorm (sum, sumsq) of the output accumulated by the epilogue
+        d.gn_sums, d.gn_hw, d.gn_groups, d.gn_slots = _p(gn_sums), gn_hw, gn_groups, gn_slots
+        d.gn_cpg = d.N // gn_groups
     ws = workspace if workspace is not None else _default_ws
     if ws is not None:
         d.workspace = ws.data_ptr()
@@ -116,6 +120,11 @@ def groupnorm_ws_floats(Bn, HW, Cc, G):
 
 def groupnorm_fwd(x, y, gamma, beta, mean, rstd, ws, Bn, HW, Cc, G, eps, silu):
     _l.call("groupnorm_fwd", _p(x), _ld(x), _p(y), _ld(y), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(ws),
+            Bn, HW, Cc, G, eps, 1 if silu else 0, stream())
+
+
+def groupnorm_fwd_sums(x, y, gamma, beta, sums, slots, mean, rstd, Bn, HW, Cc, G, eps, silu):
+    _l.call("groupnorm_fwd_sums", _p(x), _ld(x), _p(y), _ld(y), _p(gamma), _p(beta), _p(sums), slots, _p(mean), _p(rstd),
             Bn, HW, Cc, G, eps, 1 if silu else 0, stream())
 
 
@@ -319,6 +328,12 @@ def cast_f32_f16(x, y):
 def mapper_inputs(timesteps, view_params, data, nl, Bn):
     nv = 0 if view_params is None else view_params.shape[1]
     _l.call("mapper_inputs", _p(timesteps), _p(view_params), nv, _p(data), nl, Bn, stream())
+
+
+def gemm_select_split(M, N, K, batch, tile_hint, workspace_bytes):
+    fn = _l.load().vneti_gemm_select_split
+    fn.argtypes = _l.INT_FUNCS["gemm_select_split"]
+    return int(fn(M, N, K, batch, tile_hint, workspace_bytes))
 
 
 def gemm_select_tile(M, N, batch=1):
