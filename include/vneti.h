@@ -352,6 +352,31 @@ int vneti_mapper_inputs(const void* timesteps_i64, const float* view_params, int
                         int nl, int Bn, void* stream);
 int vneti_cast_f32_f16(const float* x, void* y, long long n, void* stream);
 
+
+/* ---- device-side input pipeline: the per-sample image work of training/dataset.py:238-316,700-740
+   on uint8 HWC RGB images in HBM.  Each entry restates the Pillow / torchvision routine named beside it
+   (csrc/image.hip); the random parameters are drawn on the host (compat/augment.py::draw_plan). ------------------- */
+/* Resample.c precompute_coeffs + normalize_coeffs_8bpc for one axis; filter 0 = BICUBIC (dataset.py `_resize`),
+   1 = BILINEAR (RandomResizedCrop).  bounds: 2*out_size ints, kk: out_size*ksize ints. */
+int vneti_img_resample_ksize(int in_size, int out_size, int filter);
+int vneti_img_resample_coeffs(int in_size, int out_size, int filter, int* bounds, int* kk, void* stream);
+/* one pass of ImagingResampleHorizontal_8bpc (horizontal != 0) / Vertical_8bpc; in_w = row width of `in` */
+int vneti_img_resample_pass(const void* in, int in_w, void* out, int out_h, int out_w, const int* bounds,
+                            const int* kk, int ksize, int horizontal, void* stream);
+/* Image.crop (+ Image.transpose(FLIP_LEFT_RIGHT), dataset.py:727-728) */
+int vneti_img_crop(const void* in, int in_w, int top, int left, void* out, int h, int w, int flip, void* stream);
+/* ImageEnhance in place: mode 0 Brightness, 1 Contrast (scratch8 = 8 bytes for the luma sum), 2 Color,
+   3 RandomGrayscale (alpha unused) */
+int vneti_img_enhance(void* img, int h, int w, int mode, float alpha, void* scratch8, void* stream);
+/* torchvision adjust_hue on PIL images in place: H += shift (uint8 wrap) in Pillow's HSV */
+int vneti_img_hue(void* img, int h, int w, int shift, void* stream);
+/* GaussianBlur(5) with the host-computed kernel k5 (f32), tmp = h*w*3 floats */
+int vneti_img_blur5(const void* in, void* out, float* tmp, int h, int w, const float* k5_host, void* stream);
+/* Image.rotate(NEAREST, expand=False, fillcolor): Geometry.c affine_fixed with the six 16.16 coefficients */
+int vneti_img_affine_nearest(const void* in, void* out, int h, int w, const int* a6_host, int fill, void* stream);
+/* (uint8 / 127.5 - 1) -> f32 CHW plane set (dataset.py:738-739): writes straight into the VAE's input buffer */
+int vneti_img_to_f32_chw(const void* img, float* out, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,3 +199,57 @@ def test_train_then_generate(tmp_path, monkeypatch):
                             generator=torch.Generator().manual_seed(0), output_type="np", return_dict=False)[0]
     assert out2.shape == (1, 384, 512, 3) and np.isfinite(out2).all() and out2.min() >= 0 and out2.max() <= 1
     assert np.abs(a.astype(np.int32) - (out2[0] * 255).round().astype(np.int32)).mean() < 3.0  # same seed, same image
+
+
+@pytest.mark.parametrize("aug_key,flip", [(7, True), (5, False)])
+def test_coach_device_input_pipeline_matches_host(tmp_path, aug_key, flip):
+    """cfg.data.device_input_pipeline: the same seeded run feeds the step the same pixels whether the
+    resize / flip / augmentation pipeline runs in PIL on the host or as HIP kernels on cached images, and trains."""
+    from view_neti_amd.compat import config as C
+    from view_neti_amd.compat.coach import Coach
+    root = tmp_path / "toys"
+    root.mkdir()
+    rng = np.random.RandomState(1)
+    for i in range(3):
+        a = rng.randint(0, 255, (12, 16, 3), dtype=np.uint8)
+        Image.fromarray(a).resize((160, 120), Image.BICUBIC).save(root / f"{i}.png")
+
+    def make(device_pipe, name):
+        cfg = C.parse(C.RunConfig, [
+            "--data.train_data_dir", str(root), "--data.placeholder_object_token", "<toy>", "--data.resolution", "64",
+            "--data.dataloader_num_workers", "0", "--data.augmentation_key", str(aug_key),
+            "--data.device_input_pipeline", str(device_pipe), "--model.word_embedding_dim", "128",
+            "--model.arch_view_net", "15", "--model.arch_view_disable_tl", "False", "--model.arch_mlp_hidden_dims", "64",
+            "--model.use_nested_dropout", "False", "--optim.max_train_steps", "3", "--optim.train_batch_size", "2",
+            "--optim.mixed_precision", "fp16", "--log.save_steps", "100", "--log.exp_dir", str(tmp_path / name),
+            "--log.exp_name", "run"])
+        cfg.log.exp_dir = cfg.log.exp_dir / cfg.log.exp_name
+        cfg.log.logging_dir = cfg.log.exp_dir / cfg.log.logging_dir
+        torch.manual_seed(cfg.seed)
+        c = Coach(cfg)
+        c.train_dataset.flip_p = 0.5 if flip else 0.0  # Coach never forwards flip_p (reference quirk Q10)
+        return c
+
+    host, dev = make(False, "host"), make(True, "dev")
+    assert dev.device_pipe is not None and host.device_pipe is None
+    worst = 0.0
+    for it in range(3):
+        import random
+        torch.manual_seed(1000 + it)
+        random.seed(it)  # the caption template is drawn with python's `random` (dataset.py:630)
+        bh = next(iter(host.train_dataloader))
+        torch.manual_seed(1000 + it)
+        random.seed(it)
+        bd = next(iter(dev.train_dataloader))
+        assert "pixel_values" in bh and "aug" in bd and "pixel_values" not in bd
+        assert torch.equal(bh["input_ids"], bd["input_ids"]) and torch.equal(bh["image_idx"], bd["image_idx"])
+        assert dev._pixels(bd) is None
+        torch.cuda.synchronize()
+        d = (dev.engine.pixel_values.cpu() - host._pixels(bh)).abs()
+        assert d.max().item() <= 2 / 127.5 + 1e-6, f"iteration {it}: max pixel difference {d.max().item() * 127.5:.2f} LSB"
+        worst = max(worst, (d > 1e-6).float().mean().item())
+    assert worst < 0.02, worst
+    p0 = dev.engine.params.clone()
+    dev.train()
+    assert dev.engine.opt_step.item() == 3 and not torch.equal(p0, dev.engine.params)
+    assert np.isfinite(dev.engine.loss())

@@ -55,10 +55,20 @@ def to_grayscale3(img: Image.Image) -> Image.Image:
     return Image.fromarray(np.dstack([g, g, g]), "RGB")
 
 
+def blur_kernel(sigma: float, kernel_size: int = 5) -> np.ndarray:
+    half = (kernel_size - 1) * 0.5
+    x = np.linspace(-half, half, kernel_size)
+    k = np.exp(-0.5 * (x / sigma) ** 2)
+    return (k / k.sum()).astype(np.float32)
+
+
 def gaussian_blur(img: Image.Image, kernel_size: int = 5, sigma_range=(0.1, 0.2)) -> Image.Image:
     """T.GaussianBlur: sigma ~ U(range); separable kernel on the float image with reflect padding, result
     rounded back to uint8 (functional_tensor.gaussian_blur via the PIL->tensor->PIL round trip)."""
-    sigma = float(torch.empty(1).uniform_(sigma_range[0], sigma_range[1]))
+    return blur_with_sigma(img, float(torch.empty(1).uniform_(sigma_range[0], sigma_range[1])), kernel_size)
+
+
+def blur_with_sigma(img: Image.Image, sigma: float, kernel_size: int = 5) -> Image.Image:
     half = (kernel_size - 1) * 0.5
     x = np.linspace(-half, half, kernel_size)
     k = np.exp(-0.5 * (x / sigma) ** 2)
@@ -108,45 +118,117 @@ def random_resized_crop(img: Image.Image, size: Tuple[int, int], scale: Tuple[fl
     return img.crop((j, i, j + w, i + h)).resize((size[1], size[0]), resample=Image.BILINEAR)
 
 
-# ------------------------------------------------------------------ pipelines
-def _maybe(p: float, fn: Callable[[Image.Image], Image.Image]):
-    """T.RandomApply([t], p): skipped when p < torch.rand(1)."""
-    def run(img):
-        if p < float(torch.rand(1)):
-            return img
-        return fn(img)
-    return run
+# ------------------------------------------------------------------ pipelines: draw a plan, then apply it
+# A pipeline run is split in two: `draw_plan` consumes the torch RNG exactly like the torchvision transforms do and
+# returns the concrete operations with their parameters; `apply_plan` executes them on a PIL image.  The device
+# input pipeline (engine/input_pipeline.py) executes the SAME plan with HIP kernels, so a seeded run
+# is identical on both paths by construction of the draws and bit-comparable by the kernels' parity tests.
+def _draw_jitter(b=0.04, c=0.04, s=0.04, h=0.04):
+    order = torch.randperm(4).tolist()
+    fb = float(torch.empty(1).uniform_(max(0.0, 1 - b), 1 + b))
+    fc = float(torch.empty(1).uniform_(max(0.0, 1 - c), 1 + c))
+    fs = float(torch.empty(1).uniform_(max(0.0, 1 - s), 1 + s))
+    fh = float(torch.empty(1).uniform_(-h, h))
+    return ("jitter", order, fb, fc, fs, fh)
 
 
-def _gray(p: float):
-    """T.RandomGrayscale(p): applied when torch.rand(1) < p."""
-    def run(img):
-        return to_grayscale3(img) if float(torch.rand(1)) < p else img
-    return run
+def _draw_blur(sigma_range=(0.1, 0.2)):
+    return ("blur", float(torch.empty(1).uniform_(sigma_range[0], sigma_range[1])))
+
+
+def _draw_rotation(degrees: float = 10.0):
+    return ("rotate", float(torch.empty(1).uniform_(-degrees, degrees)))
+
+
+def _draw_rrcrop(width: int, height: int, size: Tuple[int, int], scale, ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    area = height * width
+    log_ratio = (math.log(ratio[0]), math.log(ratio[1]))
+    for _ in range(10):
+        target_area = area * float(torch.empty(1).uniform_(scale[0], scale[1]))
+        aspect = math.exp(float(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])))
+        w = int(round(math.sqrt(target_area * aspect)))
+        h = int(round(math.sqrt(target_area / aspect)))
+        if 0 < w <= width and 0 < h <= height:
+            i = int(torch.randint(0, height - h + 1, size=(1,)))
+            j = int(torch.randint(0, width - w + 1, size=(1,)))
+            return ("rrcrop", i, j, h, w, size[0], size[1])
+    in_ratio = float(width) / float(height)  # fallback: central crop clamped to the ratio range
+    if in_ratio < min(ratio):
+        w, h = width, int(round(width / min(ratio)))
+    elif in_ratio > max(ratio):
+        h, w = height, int(round(height * max(ratio)))
+    else:
+        w, h = width, height
+    return ("rrcrop", (height - h) // 2, (width - w) // 2, h, w, size[0], size[1])
+
+
+# (kind, probability, arguments) per step; RandomApply skips when p < rand, RandomGrayscale applies when rand < p
+_PIPELINES = {
+    1: [("jitter", 0.75), ("gray", 0.1), ("blur", 0.10), ("rotate", 0.75), ("rrcrop", (0.85, 1.15))],
+    2: [("jitter", 0.75), ("gray", 0.1), ("blur", 0.10)],
+    3: [("jitter", 0.75), ("gray", 0.1), ("blur", 0.10), ("rotate", 0.75)],
+    4: [("jitter", 0.75), ("gray", 0.1), ("blur", 0.10), ("rrcrop", (0.85, 1.15))],
+    5: [("jitter", 0.75), ("blur", 0.25), ("rrcrop", (0.95, 1.05))],
+    6: [("jitter", 0.75), ("gray", 0.1), ("blur", 0.10), ("rotate", 0.75), ("rrcrop", (0.70, 1.3))],
+    7: [("jitter", 0.75), ("blur", 0.2), ("rotate", 0.75), ("rrcrop", (0.70, 1.3))],
+    8: [("jitter", 0.75), ("gray", 0.1), ("blur", 0.10)],
+}
+
+
+def draw_plan(key: int, size: Tuple[int, int], width: int, height: int) -> List[tuple]:
+    """The random draws of one pipeline run on a width x height image (size = (height, width) target of the crops,
+    dataset.py:229-236), in torchvision's order."""
+    if key not in _PIPELINES:
+        raise ValueError(f"unknown augmentation_key {key}")  # the reference does a bare `raise` (dataset.py:315)
+    plan: List[tuple] = []
+    for kind, arg in _PIPELINES[key]:
+        if kind == "gray":
+            if float(torch.rand(1)) < arg:
+                plan.append(("gray",))
+        elif kind == "rrcrop":
+            op = _draw_rrcrop(width, height, size, arg)
+            plan.append(op)
+            height, width = op[5], op[6]
+        else:
+            if arg < float(torch.rand(1)):  # T.RandomApply([t], p)
+                continue
+            plan.append({"jitter": _draw_jitter, "blur": _draw_blur, "rotate": _draw_rotation}[kind]())
+    return plan
+
+
+def apply_plan(img: Image.Image, plan: List[tuple], fill: int = 1) -> Image.Image:
+    for op in plan:
+        kind = op[0]
+        if kind == "jitter":
+            _, order, fb, fc, fs, fh = op
+            for fn_id in order:
+                if fn_id == 0:
+                    img = ImageEnhance.Brightness(img).enhance(fb)
+                elif fn_id == 1:
+                    img = ImageEnhance.Contrast(img).enhance(fc)
+                elif fn_id == 2:
+                    img = ImageEnhance.Color(img).enhance(fs)
+                else:
+                    img = adjust_hue(img, fh)
+        elif kind == "gray":
+            img = to_grayscale3(img)
+        elif kind == "blur":
+            img = blur_with_sigma(img, op[1])
+        elif kind == "rotate":
+            img = img.rotate(op[1], resample=Image.NEAREST, expand=False, fillcolor=(fill,) * len(img.getbands()))
+        elif kind == "rrcrop":
+            _, i, j, h, w, oh, ow = op
+            img = img.crop((j, i, j + w, i + h)).resize((ow, oh), resample=Image.BILINEAR)
+        else:
+            raise ValueError(kind)
+    return img
 
 
 def build_augmentations(key: int, size: Tuple[int, int]) -> Callable[[Image.Image], Image.Image]:
     """size = (height, width) as in dataset.py:229-236."""
-    jitter = _maybe(0.75, color_jitter)
-    rot = _maybe(0.75, random_rotation)
-    blur = lambda p: _maybe(p, gaussian_blur)
-    crop = lambda lo, hi: (lambda img: random_resized_crop(img, size, (lo, hi)))
-    table = {
-        1: [jitter, _gray(0.1), blur(0.10), rot, crop(0.85, 1.15)],
-        2: [jitter, _gray(0.1), blur(0.10)],
-        3: [jitter, _gray(0.1), blur(0.10), rot],
-        4: [jitter, _gray(0.1), blur(0.10), crop(0.85, 1.15)],
-        5: [jitter, blur(0.25), crop(0.95, 1.05)],
-        6: [jitter, _gray(0.1), blur(0.10), rot, crop(0.70, 1.3)],
-        7: [jitter, blur(0.2), rot, crop(0.70, 1.3)],
-        8: [jitter, _gray(0.1), blur(0.10)],
-    }
-    if key not in table:
-        raise ValueError(f"unknown augmentation_key {key}")  # the reference does a bare `raise` (dataset.py:315)
-    steps: List[Callable] = table[key]
+    if key not in _PIPELINES:
+        raise ValueError(f"unknown augmentation_key {key}")
 
     def run(img: Image.Image) -> Image.Image:
-        for t in steps:
-            img = t(img)
-        return img
+        return apply_plan(img, draw_plan(key, size, img.size[0], img.size[1]))
     return run

@@ -111,7 +111,26 @@ class Coach:
             gen.manual_seed(parallel.data_seed(cfg.seed, self.rank))
         self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=bs, shuffle=True,
                                                             num_workers=cfg.data.dataloader_num_workers,
-                                                            drop_last=True, generator=gen)
+                                                            drop_last=True, generator=gen,
+                                                            collate_fn=TextualInversionDataset.collate)
+        self.device_pipe, self._device_sources = None, {}
+        if getattr(cfg.data, "device_input_pipeline", False):
+            from ..engine.input_pipeline import DeviceImagePipeline
+            _, _, ph, pw = self.engine.pixel_values.shape
+            self.device_pipe = DeviceImagePipeline(ph, pw, device)
+
+    def _pixels(self, batch):
+        """host path: the collated f32 batch; device path (cfg.data.device_input_pipeline): the plans drawn by the
+        dataset are executed by HIP kernels straight into the engine's pixel buffer (returns None = already there)"""
+        if "aug" not in batch:
+            return batch["pixel_values"]
+        ds, pipe = self.train_dataset, self.device_pipe
+        for b, a in enumerate(batch["aug"]):
+            src = self._device_sources.get(a["path"])
+            if src is None:
+                src = self._device_sources[a["path"]] = pipe.upload(ds.load_source(a["path"]))
+            pipe.run(src, self.engine.pixel_values[b], resize=ds.target_size(), flip=a["flip"], plan=a["plan"])
+        return None
 
     # ------------------------------------------------------------------ set-up
     def _setup_logging(self):
@@ -146,7 +165,8 @@ class Coach:
             train_data_subsets=d.train_data_subsets, placeholder_object_tokens=d.placeholder_object_tokens,
             fixed_object_token_or_path=d.fixed_object_token_or_path, dtu_lighting=d.dtu_lighting,
             dtu_subset=d.dtu_subset, caption_strategy=d.caption_strategy, dtu_preprocess_key=d.dtu_preprocess_key,
-            augmentation_key=d.augmentation_key)  # flip_p is NOT forwarded — reference quirk Q10
+            augmentation_key=d.augmentation_key,  # flip_p is NOT forwarded — reference quirk Q10
+            device_pipeline=bool(getattr(d, "device_input_pipeline", False)))
 
     def _add_concept_tokens(self):
         ds, tok = self.train_dataset, self.tokenizer
@@ -266,7 +286,7 @@ class Coach:
                 ids_obj = batch["input_ids_placeholder_object"]
                 if not bool((ids_obj == ids_obj[0]).all()):
                     raise ValueError("a batch must hold a single object token (net_clip_text_embedding.py:67-68)")
-                eng.set_batch(batch["pixel_values"], batch["input_ids"], ids_obj, batch["input_ids_placeholder_view"],
+                eng.set_batch(self._pixels(batch), batch["input_ids"], ids_obj, batch["input_ids_placeholder_view"],
                               self._view_params(batch["input_ids_placeholder_view"]),
                               object_index=self.object_slot[int(ids_obj[0])])
                 if not captured:

@@ -65,6 +65,9 @@ class DataConfig:
     dtu_lighting: str = 3
     dtu_subset: int = -2
     augmentation_key: int = 0
+    # extension (not in the reference): run resize / flip / augmentations as HIP kernels on images cached in HBM
+    # (engine/input_pipeline.py); same random draws, same pixels as the host path
+    device_input_pipeline: bool = False
     # filled at run time (a plain class attribute in the reference, config.py:64)
     placeholder_view_tokens: Optional[List[str]] = None
 

@@ -30,8 +30,9 @@ class TextualInversionDataset(torch.utils.data.Dataset):
                  fixed_object_token_or_path=None, size: int = 512, repeats: int = 100, flip_p: float = 0.0,
                  set: str = "train", placeholder_object_token: str = "*", dtu_lighting: str = "3", dtu_subset: int = 0,
                  caption_strategy: int = 0, dtu_preprocess_key: int = 0, augmentation_key: int = 0,
-                 center_crop: bool = False):
+                 center_crop: bool = False, device_pipeline: bool = False):
         self.learnable_mode = learnable_mode
+        self.device_pipeline = device_pipeline  # images are produced on the GPU from the plan this dataset draws
         self.data_root = Path(data_root)
         self.tokenizer = tokenizer
         self.size = size
@@ -58,6 +59,7 @@ class TextualInversionDataset(torch.utils.data.Dataset):
                 raise NotImplementedError("augmentation with dtu_preprocess_key 2 is undefined in the reference "
                                           "(dataset.py:231-236 leaves `size` unset)")
             self.augmentations = build_augmentations(augmentation_key, aug_size)
+            self.aug_size = aug_size
         if learnable_mode != 3:
             paths = filter_paths_imgs(sorted(self.data_root.glob("*")))
             if camera_representation == "dtu-12d" and learnable_mode != 0:
@@ -185,6 +187,49 @@ class TextualInversionDataset(torch.utils.data.Dataset):
             return image
         return image.resize((self.size, self.size), resample=Image.BICUBIC)
 
+    def _source_array(self, image: Image.Image) -> np.ndarray:
+        arr = np.array(image).astype(np.uint8)
+        if self.center_crop:
+            h, w = arr.shape[:2]
+            c = min(h, w)
+            arr = arr[(h - c) // 2:(h + c) // 2, (w - c) // 2:(w + c) // 2]
+        return arr
+
+    def _source_hw(self, hw):
+        if self.center_crop:
+            c = min(hw)
+            return (c, c)
+        return tuple(hw)
+
+    def target_size(self):
+        """(height, width) `_resize` produces, None when it leaves the image alone (llff)"""
+        if "dtu" in str(self.data_root):
+            return {0: (512, 512), 1: (384, 512), 2: (576, 768)}[self.dtu_preprocess_key]
+        if "llff" in str(self.data_root):
+            return None
+        return (self.size, self.size)
+
+    def load_source(self, path: str) -> np.ndarray:
+        """the uint8 image `_resize` starts from (RGB, centre crop, the 400 black rows of dtu_preprocess_key 0):
+        what the device pipeline caches in HBM"""
+        image = Image.open(path)
+        if image.mode != "RGB":
+            image = image.convert("RGB")
+        arr = self._source_array(image)
+        if "dtu" in str(self.data_root) and self.dtu_preprocess_key == 0:
+            arr = np.concatenate([arr, np.zeros((400, arr.shape[1], 3), np.uint8)], 0)
+        return arr
+
+    @staticmethod
+    def collate(samples):
+        """default collation, except that the augmentation plans stay python objects"""
+        from torch.utils.data import default_collate
+        aug = [s.pop("aug") for s in samples] if "aug" in samples[0] else None
+        batch = default_collate(samples)
+        if aug is not None:
+            batch["aug"] = aug
+        return batch
+
     def __getitem__(self, i: int) -> Dict[str, Any]:
         if self.learnable_mode != 3:
             paths = self.image_paths
@@ -196,8 +241,8 @@ class TextualInversionDataset(torch.utils.data.Dataset):
             obj_token = self.lookup_object_to_placeholder_object_token[cur]
             idx = i % len(paths)
         path = paths[idx]
-        image = Image.open(path)
-        if image.mode != "RGB":
+        image = Image.open(path)  # lazy: decoded only on the host path below
+        if image.mode != "RGB" and not self.device_pipeline:
             image = image.convert("RGB")
         ex: Dict[str, Any] = {"image_idx": idx}
         template = random.choice(self.templates)  # drawn even when unused, like the reference (:630)
@@ -218,12 +263,18 @@ class TextualInversionDataset(torch.utils.data.Dataset):
             ex["input_ids_placeholder_view"] = torch.tensor(self.tokenizer.convert_tokens_to_ids(view_token))
         ex["input_ids"] = self.tokenizer(ex["text"], padding="max_length", truncation=True,
                                          max_length=self.tokenizer.model_max_length, return_tensors="pt").input_ids[0]
-        arr = np.array(image).astype(np.uint8)
-        if self.center_crop:
-            h, w = arr.shape[:2]
-            c = min(h, w)
-            arr = arr[(h - c) // 2:(h + c) // 2, (w - c) // 2:(w + c) // 2]
-        image = self._resize(Image.fromarray(arr))
+        if self.device_pipeline:
+            # same random draws in the same order as the host path below; the pixels are produced by
+            # engine/input_pipeline.py in the training process from the cached source image
+            flip = bool(self.learnable_mode == 0 and self.flip_p > 0 and torch.rand(1).item() < self.flip_p)
+            plan = []
+            if self.augmentations is not None:
+                from .augment import draw_plan
+                tgt = self.target_size() or self._source_hw(image.size[::-1])
+                plan = draw_plan(self.augmentation_key, self.aug_size, tgt[1], tgt[0])
+            ex["aug"] = dict(path=str(path), flip=flip, plan=plan)
+            return ex
+        image = self._resize(Image.fromarray(self._source_array(image)))
         if self.learnable_mode == 0 and self.flip_p > 0 and torch.rand(1).item() < self.flip_p:
             image = image.transpose(Image.FLIP_LEFT_RIGHT)
         if self.augmentations is not None:

@@ -140,7 +140,8 @@ class TrainStepEngine:
             raise ValueError("the object mapper may not change inside a gradient-accumulation group")
         self.active_object = object_index
         self.obj_slot.fill_(object_index)
-        self.pixel_values.copy_(pixel_values, non_blocking=True)
+        if pixel_values is not None:  # None: the device input pipeline already wrote self.pixel_values
+            self.pixel_values.copy_(pixel_values, non_blocking=True)
         self.text.set_batch(input_ids, placeholder_object, placeholder_view, view_params)
 
     def train(self, mode: bool = True):

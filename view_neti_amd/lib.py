@@ -120,6 +120,14 @@ SIGNATURES = {
     "im2col3x3_small": [c_vp, c_int, c_ll, c_ll, c_ll, c_ll, c_vp] + [c_int] * 9 + [c_vp],
     "transpose_f16": [c_vp, c_ll, c_ll, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
     "transpose_f16_multi": [c_vp, c_int, c_vp],
+    "img_resample_coeffs": [c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "img_resample_pass": [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
+    "img_crop": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],
+    "img_enhance": [c_vp, c_int, c_int, c_int, c_f, c_vp, c_vp],
+    "img_hue": [c_vp, c_int, c_int, c_int, c_vp],
+    "img_blur5": [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp],
+    "img_affine_nearest": [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp],
+    "img_to_f32_chw": [c_vp, c_vp, c_int, c_int, c_vp],
     "groupnorm_fwd_sums": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                            c_f, c_int, c_vp],
     "groupnorm_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
@@ -172,7 +180,8 @@ SIGNATURES = {
     "mapper_inputs": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp],
 }
 
-INT_FUNCS = {"gemm_select_tile": [c_int] * 3, "gemm_select_split": [c_int] * 5 + [c_ll]}
+INT_FUNCS = {"gemm_select_tile": [c_int] * 3, "gemm_select_split": [c_int] * 5 + [c_ll],
+             "img_resample_ksize": [c_int] * 3}
 
 LL_FUNCS = {
     "mapper_num_params": [c_int] * 4,

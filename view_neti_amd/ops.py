@@ -340,3 +340,47 @@ def gemm_select_tile(M, N, batch=1):
     fn = _l.load().vneti_gemm_select_tile
     fn.argtypes = _l.INT_FUNCS["gemm_select_tile"]
     return int(fn(M, N, batch))
+
+
+# ------------------------------------------------------------------ device-side input pipeline (csrc/image.hip)
+def img_resample_ksize(in_size, out_size, filt):
+    fn = _l.load().vneti_img_resample_ksize
+    fn.argtypes = _l.INT_FUNCS["img_resample_ksize"]
+    return int(fn(in_size, out_size, filt))
+
+
+def img_resample_coeffs(in_size, out_size, filt, bounds, kk):
+    _l.call("img_resample_coeffs", in_size, out_size, filt, _p(bounds), _p(kk), stream())
+
+
+def img_resample_pass(inp, in_w, out, out_h, out_w, bounds, kk, ksize, horizontal):
+    _l.call("img_resample_pass", _p(inp), in_w, _p(out), out_h, out_w, _p(bounds), _p(kk), ksize, 1 if horizontal else 0,
+            stream())
+
+
+def img_crop(inp, in_w, top, left, out, h, w, flip=False):
+    _l.call("img_crop", _p(inp), in_w, top, left, _p(out), h, w, 1 if flip else 0, stream())
+
+
+def img_enhance(img, h, w, mode, alpha, scratch8):
+    _l.call("img_enhance", _p(img), h, w, mode, float(alpha), _p(scratch8), stream())
+
+
+def img_hue(img, h, w, shift):
+    _l.call("img_hue", _p(img), h, w, int(shift), stream())
+
+
+def img_blur5(inp, out, tmp, h, w, k5):
+    import ctypes
+    arr = (ctypes.c_float * 5)(*[float(x) for x in k5])
+    _l.call("img_blur5", _p(inp), _p(out), _p(tmp), h, w, ctypes.addressof(arr), stream())
+
+
+def img_affine_nearest(inp, out, h, w, a6, fill):
+    import ctypes
+    arr = (ctypes.c_int * 6)(*[int(x) for x in a6])
+    _l.call("img_affine_nearest", _p(inp), _p(out), h, w, ctypes.addressof(arr), int(fill), stream())
+
+
+def img_to_f32_chw(img, out, h, w):
+    _l.call("img_to_f32_chw", _p(img), _p(out), h, w, stream())
