@@ -102,3 +102,39 @@ class ValidationHandler:
                 grid.save(exp / f"{stem}_numseeds_{len(seeds)}_upsample_{ev.dtu_upsample_key}{tag}_seed_{seed}.png")
         torch.save(result[tokens[0]] if len(tokens) == 1 else result,
                    exp / f"{stem}_numseeds_{len(seeds)}_upsample_{ev.dtu_upsample_key}.pt")
+        if cfg.data.camera_representation == "dtu-12d":
+            self._dtu_metrics(step, stem, result, seeds)
+
+    def _dtu_metrics(self, step: int, stem: str, result, seeds):
+        """validate.py:123-186: masked MSE / PSNR / SSIM of the generated views against the scene's ground truth
+        (compat/dtu_metrics.py).  Runs when all the evaluation views of the split were generated at a 3:4 aspect and the
+        ground-truth images are on disk; object masks default to all-white when the IDR masks are absent."""
+        import json
+        from . import dtu_metrics as dm
+        cfg, coach = self.cfg, self.coach
+        cam_idxs, _, _ = dm.get_cam_idxs(cfg.data.dtu_subset)
+        summary = {}
+        for obj, per_cam in result.items():
+            if set(per_cam) != set(cam_idxs):
+                continue
+            h, w = per_cam[cam_idxs[0]][0].shape[:2]
+            if h / w != 0.75:
+                continue
+            if cfg.learnable_mode == 3:
+                scan_id = obj[5:-1]
+                scene = Path(cfg.data.train_data_dir) / f"scan{scan_id}"
+            else:
+                scene, scan_id = Path(cfg.data.train_data_dir), Path(cfg.data.train_data_dir).stem[4:]
+            if not scene.exists():
+                continue
+            pred = {c: np.stack(per_cam[c]) for c in cam_idxs}
+            try:
+                res = dm.evaluate_dtu_predictions(pred, scene, cfg.data.dtu_subset, cfg.data.dtu_lighting, 1, seeds,
+                                                  scan_id=scan_id, make_figures=False)
+            except FileNotFoundError:
+                continue
+            summary[obj] = {k: v for k, v in res.items() if k.endswith("_mean")}
+            coach.log(f"validation step {step} {obj}: " + "  ".join(f"{k} {v:.4f}" for k, v in summary[obj].items()))
+        if summary:
+            with open(Path(cfg.log.exp_dir) / f"{stem}_metrics.json", "w") as f:
+                json.dump(summary, f, indent=1)
