@@ -264,8 +264,12 @@ def test_im2col_small_and_conv_in():
 # ------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("Cc,HW", [(320, 256), (128, 1024), (2560, 64), (960, 100), (320, 4096), (128, 40000)])
 @pytest.mark.parametrize("silu", [True, False])
-def test_groupnorm_fwd_bwd(Cc, HW, silu):
+@pytest.mark.parametrize("three_launch", [False, True])
+def test_groupnorm_fwd_bwd(Cc, HW, silu, three_launch, monkeypatch):
+    """both forms: the one-launch kernel small (sample, group) slices dispatch to, and the stats/finalize/apply form"""
     ops = _ops()
+    if three_launch:
+        monkeypatch.setenv("VNETI_GN_NO_SMALL", "1")
     Bn, G, eps = 2, 32, 1e-5
     x = (rnd(Bn, HW, Cc, seed=19).float() * 1.5 + 0.3).half()
     gamma = 1 + 0.1 * rnd(Cc, seed=20, dtype=torch.float32)

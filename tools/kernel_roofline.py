@@ -1,0 +1,91 @@
+"""Dev tool: every launch class of the train step against ITS roofline (SURVEY §8d "per-kernel bar"): launches are
+replayed in schedule order (so each starts with its operands evicted by its predecessors, as inside the step), timed
+with HIP events per class, and divided into the class's algorithmic FLOPs (MFMA kernels, peak 2.5 PF dense f16) or
+bytes (HBM kernels, peak 8 TB/s).  Writes gpurun_out/<tag>_kernel_roofline.json and prints a markdown table.
+   python tools/kernel_roofline.py r01f"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse
+import torch
+import bench
+from view_neti_amd import ops
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01x"
+args = argparse.Namespace(model="sd15", batch=4, resolution=512)
+_, eng = bench.build_engine(args, 0, 1)
+eng.step_eager(); torch.cuda.synchronize()
+PF, TB = 2500.0, 8.0
+
+
+def cost(f):
+    """(class, flops, bytes) of one launch; None = not classified (closures of the backward builders etc.)"""
+    fn, a, kw = getattr(f, "func", None), getattr(f, "args", ()), getattr(f, "keywords", {}) or {}
+    if fn is ops.gemm:
+        A, B = a[0], a[1]
+        M = kw.get("M") or A.shape[-2]
+        N, K = kw.get("N") or B.shape[-2], kw.get("K") or B.shape[-1]
+        return ("gemm / implicit-GEMM conv", 2.0 * M * N * K * (kw.get("batch") or 1), 0)
+    if fn in (ops.attn_fwd, ops.attn_bwd_dq, ops.attn_bwd_dkv):
+        i = {ops.attn_fwd: 5, ops.attn_bwd_dq: 7, ops.attn_bwd_dkv: 8}[fn]
+        Bn, H, Nq, Nk, D = a[i:i + 5]
+        causal = a[i + 6]
+        mm = {ops.attn_fwd: 2, ops.attn_bwd_dq: 3, ops.attn_bwd_dkv: 4}[fn]  # matmuls of Nq x Nk x D executed
+        name = {ops.attn_fwd: "attention fwd", ops.attn_bwd_dq: "attention bwd dQ", ops.attn_bwd_dkv: "attention bwd dK/dV"}[fn]
+        return (name, mm * 2.0 * Bn * H * Nq * Nk * D * (0.5 if causal else 1.0), 0)
+    if fn in (ops.groupnorm_fwd, ops.groupnorm_fwd_sums):
+        Bn, HW, C = (a[7], a[8], a[9]) if fn is ops.groupnorm_fwd else (a[8], a[9], a[10])
+        return ("GroupNorm(+SiLU) fwd" + (" (stats in producer)" if fn is ops.groupnorm_fwd_sums else ""), 0, 2.0 * Bn * HW * C * 2)
+    if fn is ops.layernorm_fwd:
+        x, y = a[0], a[1]
+        return ("LayerNorm fwd", 0, x.numel() * x.element_size() + y.numel() * y.element_size())
+    if fn is ops.geglu_fwd:
+        return ("GEGLU fwd", 0, a[0].numel() * 2 + a[1].numel() * 2)
+    if fn is ops.geglu_bwd:
+        return ("GEGLU bwd", 0, a[0].numel() * 2 + 2 * a[1].numel() * 2)
+    return None
+
+
+launches = eng.launches()
+classes = {}
+for f in launches:
+    c = cost(f)
+    name = c[0] if c else "other (GN/LN backward closures, glue)"
+    d = classes.setdefault(name, dict(fs=[], flops=0.0, bytes=0.0))
+    d["fs"].append(f)
+    if c:
+        d["flops"] += c[1]; d["bytes"] += c[2]
+# time: replay the whole list in order, recording events only around the launches of one class at a time
+out = {}
+for name, d in classes.items():
+    mine = set(id(f) for f in d["fs"])
+    tot = 0.0
+    for rep in range(3):
+        evs = []
+        for f in launches:
+            if id(f) in mine:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); f(); e.record(); evs.append((s, e))
+            else:
+                f()
+        torch.cuda.synchronize()
+        if rep:
+            tot += sum(s.elapsed_time(e) for s, e in evs)
+    ms = tot / 2
+    r = dict(launches=len(d["fs"]), ms_per_step=ms)
+    if d["flops"]:
+        r.update(bound="mfma", algorithmic_gflop=d["flops"] / 1e9, achieved=d["flops"] / (ms * 1e-3) / 1e12, peak=PF, unit="TFLOP/s")
+        r["frac"] = r["achieved"] / PF
+    elif d["bytes"]:
+        r.update(bound="hbm", algorithmic_mb=d["bytes"] / 1e6, achieved=d["bytes"] / (ms * 1e-3) / 1e12, peak=TB, unit="TB/s")
+        r["frac"] = r["achieved"] / TB
+    out[name] = r
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open(f"gpurun_out/{tag}_kernel_roofline.json", "w"), indent=1)
+print("| launch class | launches/step | ms/step | algorithmic cost | achieved | of peak |")
+print("|---|---|---|---|---|---|")
+for name, r in sorted(out.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+    if "frac" in r:
+        costs = f"{r['algorithmic_gflop']/1e3:.2f} TFLOP" if r["bound"] == "mfma" else f"{r['algorithmic_mb']/1e3:.2f} GB"
+        print(f"| {name} | {r['launches']} | {r['ms_per_step']:.2f} | {costs} | {r['achieved']:.2f} {r['unit']} | {r['frac']:.2f} of {r['peak']:g} |")
+    else:
+        print(f"| {name} | {r['launches']} | {r['ms_per_step']:.2f} | — | — | — |")

@@ -277,6 +277,177 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// One-launch GroupNorm for small tensors (the low-resolution UNet levels): block (g, b) owns one
+// group of one sample, walks it twice -- statistics, then apply; the second walk hits L2 -- instead of the three
+// launches above.  At these sizes the three-launch form is launch-latency-bound (the 45 un-fused forward GroupNorms of
+// the SD-1.5 step moved 0.42 GB in 0.86 ms), one launch is not.  Elements are addressed as half2 pairs (cpg is even;
+// a group's channel range is only 4-byte aligned when cpg = 10).
+// ------------------------------------------------------------------------------------------
+template <bool BWD, bool SILU>
+__global__ __launch_bounds__(512) void gn_small_kernel(int HW, int C, int G, const half_t* __restrict__ x, long long ldx,
+                                                       const half_t* __restrict__ dy, long long lddy,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, float eps,
+                                                       half_t* __restrict__ out, long long ldo,
+                                                       const half_t* __restrict__ accum, long long ldacc) {
+  __shared__ double red[2][8];
+  __shared__ float stat[2];
+  __shared__ float sga[128], sbe[128];  // this group's gamma / beta (cpg <= 128)
+  const int gi = blockIdx.x, b = blockIdx.y;
+  const int cpg = C / G, hp = cpg / 2;  // pairs per row
+  const int c0 = gi * cpg;
+  const int total = HW * hp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NTH = blockDim.x;
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  constexpr int U = 8;  // independent 4-byte loads in flight per thread and tensor
+  for (int i = threadIdx.x; i < cpg; i += NTH) {
+    sga[i] = gamma[c0 + i];
+    sbe[i] = beta[c0 + i];
+  }
+  float m = 0.f, rs = 0.f;
+  if (BWD) {
+    m = mean[b * G + gi];
+    rs = rstd[b * G + gi];
+  }
+  __syncthreads();
+  const half_t* xb = x + (long long)b * HW * ldx + c0;
+  const half_t* dyb = BWD ? dy + (long long)b * HW * lddy + c0 : nullptr;
+  // ---- pass 1: FWD (sum, sum of squares); BWD (sum dxh, sum dxh * xhat)
+  float s0 = 0.f, s1 = 0.f;
+  for (int base = threadIdx.x; base < total; base += NTH * U) {
+    half2_t xv[U], dv[U];
+    int cps[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = base + u * NTH;
+      const int r = p / hp;
+      cps[u] = (p - r * hp) * 2;
+      xv[u] = half2_t{(half_t)0.f, (half_t)0.f};
+      dv[u] = xv[u];
+      if (p < total) {
+        xv[u] = *reinterpret_cast<const half2_t*>(xb + (long long)r * ldx + cps[u]);
+        if (BWD) dv[u] = *reinterpret_cast<const half2_t*>(dyb + (long long)r * lddy + cps[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (base + u * NTH >= total) break;
+      if (!BWD) {
+        const float v0 = (float)xv[u][0], v1 = (float)xv[u][1];
+        s0 += v0 + v1;
+        s1 += v0 * v0 + v1 * v1;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float ga = sga[cps[u] + j];
+          const float xh = ((float)xv[u][j] - m) * rs;
+          float d = (float)dv[u][j];
+          if (SILU) {
+            const float z = xh * ga + sbe[cps[u] + j];
+            const float sg = vn_sigmoid(z);
+            d *= sg * (1.f + z * (1.f - sg));
+          }
+          const float dxh = d * ga;
+          s0 += dxh;
+          s1 += dxh * xh;
+        }
+      }
+    }
+  }
+  double d0 = (double)s0, d1 = (double)s1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    d0 += __shfl_xor(d0, off);
+    d1 += __shfl_xor(d1, off);
+  }
+  if (lane == 0) {
+    red[0][wave] = d0;
+    red[1][wave] = d1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int w = 0; w < (NTH >> 6); ++w) {
+      t0 += red[0][w];
+      t1 += red[1][w];
+    }
+    const double n = (double)HW * cpg;
+    if (!BWD) {
+      const double mu = t0 / n;
+      double var = t1 / n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      stat[0] = (float)mu;
+      stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+      mean[b * G + gi] = stat[0];
+      rstd[b * G + gi] = stat[1];
+    } else {
+      stat[0] = (float)(t0 / n);
+      stat[1] = (float)(t1 / n);
+    }
+  }
+  __syncthreads();
+  const float a0 = stat[0], a1 = stat[1];  // FWD: mean, rstd;  BWD: c1, c2
+  // ---- pass 2: apply (x and dy come back from L2)
+  half_t* ob = out + (long long)b * HW * ldo + c0;
+  const half_t* ab = accum ? accum + (long long)b * HW * ldacc + c0 : nullptr;
+  for (int base = threadIdx.x; base < total; base += NTH * U) {
+    half2_t xv[U], dv[U], av[U];
+    int cps[U], rows[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = base + u * NTH;
+      rows[u] = p / hp;
+      cps[u] = (p - rows[u] * hp) * 2;
+      xv[u] = half2_t{(half_t)0.f, (half_t)0.f};
+      dv[u] = xv[u];
+      av[u] = xv[u];
+      if (p < total) {
+        xv[u] = *reinterpret_cast<const half2_t*>(xb + (long long)rows[u] * ldx + cps[u]);
+        if (BWD) {
+          dv[u] = *reinterpret_cast<const half2_t*>(dyb + (long long)rows[u] * lddy + cps[u]);
+          if (ab) av[u] = *reinterpret_cast<const half2_t*>(ab + (long long)rows[u] * ldacc + cps[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (base + u * NTH >= total) break;
+      half2_t ov;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float ga = sga[cps[u] + j], be = sbe[cps[u] + j];
+        if (!BWD) {
+          float z = ((float)xv[u][j] - a0) * a1 * ga + be;
+          if (SILU) z = vn_silu(z);
+          ov[j] = (half_t)z;
+        } else {
+          const float xh = ((float)xv[u][j] - m) * rs;
+          float d = (float)dv[u][j];
+          if (SILU) {
+            const float z = xh * ga + be;
+            const float sg = vn_sigmoid(z);
+            d *= sg * (1.f + z * (1.f - sg));
+          }
+          float dx = rs * (d * ga - a0 - xh * a1);
+          if (ab) dx += (float)av[u][j];
+          ov[j] = (half_t)dx;
+        }
+      }
+      *reinterpret_cast<half2_t*>(ob + (long long)rows[u] * ldo + cps[u]) = ov;
+    }
+  }
+}
+
+// one launch where it measures faster than three (tools/lab/gn_paths.py, bs=4: slices <= 40 KiB forward, <= 32 KiB
+// backward -- the 8x8 and 16x16 levels and the narrow 32x32 layers; 128 blocks cannot stream the bigger ones fast enough)
+inline bool gn_use_small(int Bn, int HW, int C, int G, bool bwd) {
+  const int cpg = C / G;
+  if (cpg % 2 != 0 || cpg > 128 || getenv("VNETI_GN_NO_SMALL")) return false;
+  return (long long)HW * cpg * 2 <= (bwd ? 32 : 40) * 1024 && Bn * G >= 64;
+}
+
 int gn_geom(GNGeom& g, int Bn, int HW, int C, int G) {
   if (Bn <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || C % G != 0 || C % 8 != 0) return -1;
   g.Bn = Bn;
@@ -517,6 +688,17 @@ extern "C" int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long l
   VN_REQUIRE(x && y && gamma && beta && mean && rstd && ws, "groupnorm_fwd: null pointer");
   VN_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "groupnorm_fwd: ld must be a multiple of 8");
   hipStream_t st = (hipStream_t)stream;
+  if (gn_use_small(Bn, HW, C, G, false)) {
+    if (silu)
+      hipLaunchKernelGGL((gn_small_kernel<false, true>), dim3(G, Bn), dim3(512), 0, st, HW, C, G, (const half_t*)x, ldx,
+                         (const half_t*)nullptr, 0LL, gamma, beta, mean, rstd, eps, (half_t*)y, ldy,
+                         (const half_t*)nullptr, 0LL);
+    else
+      hipLaunchKernelGGL((gn_small_kernel<false, false>), dim3(G, Bn), dim3(512), 0, st, HW, C, G, (const half_t*)x, ldx,
+                         (const half_t*)nullptr, 0LL, gamma, beta, mean, rstd, eps, (half_t*)y, ldy,
+                         (const half_t*)nullptr, 0LL);
+    return vneti_check_launch("groupnorm_fwd");
+  }
   dim3 grid(g.nslab, Bn);
   hipLaunchKernelGGL((gn_stats_kernel<false, false>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
                      (const half_t*)nullptr, 0LL, gamma, beta, (const float*)nullptr, (const float*)nullptr, ws);
@@ -563,6 +745,17 @@ extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x
   VN_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && ws, "groupnorm_bwd: null pointer");
   VN_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldacc % 8 == 0, "groupnorm_bwd: ld % 8 != 0");
   hipStream_t st = (hipStream_t)stream;
+  if (gn_use_small(Bn, HW, C, G, true)) {
+    if (silu)
+      hipLaunchKernelGGL((gn_small_kernel<true, true>), dim3(G, Bn), dim3(512), 0, st, HW, C, G, (const half_t*)x, ldx,
+                         (const half_t*)dy, lddy, gamma, beta, const_cast<float*>(mean), const_cast<float*>(rstd), 0.f,
+                         (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc);
+    else
+      hipLaunchKernelGGL((gn_small_kernel<true, false>), dim3(G, Bn), dim3(512), 0, st, HW, C, G, (const half_t*)x, ldx,
+                         (const half_t*)dy, lddy, gamma, beta, const_cast<float*>(mean), const_cast<float*>(rstd), 0.f,
+                         (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc);
+    return vneti_check_launch("groupnorm_bwd");
+  }
   dim3 grid(g.nslab, Bn);
   float* c1 = ws + (long long)Bn * g.nslab * 2 * G;
   float* c2 = c1 + (long long)Bn * G;
