@@ -238,7 +238,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
       c1hi = c1[b * g.G + g1];
       c2hi = c2[b * g.G + g1];
     }
-    for (int r = r0 + ty; r < r1; r += g.TY) {
+    int r = r0 + ty;
+    if (!BWD) {
+      // forward: four rows in flight per thread (a single 16-byte load per trip leaves HBM latency exposed:
+      // 3.5 TB/s measured on the VAE's 512x512x128 tensors)
+      for (; r + 3 * g.TY < r1; r += 4 * g.TY) {
+        half8 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          xv[u] = *reinterpret_cast<const half8*>(x + ((long long)b * g.HW + r + u * g.TY) * ldx + ch0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          half8 ov;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool lo = j < split;
+            float xh = ((float)xv[u][j] - (lo ? mlo : mhi)) * (lo ? rlo : rhi);
+            float z = xh * ga[j] + be[j];
+            if (SILU) z = vn_silu(z);
+            ov[j] = (half_t)z;
+          }
+          *reinterpret_cast<half8*>(out + ((long long)b * g.HW + r + u * g.TY) * ldo + ch0) = ov;
+        }
+      }
+    }
+    for (; r < r1; r += g.TY) {
       const long long row = (long long)b * g.HW + r;
       half8 xv = *reinterpret_cast<const half8*>(x + row * ldx + ch0);
       half8 ov;
