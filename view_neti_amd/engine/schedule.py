@@ -120,6 +120,8 @@ class Schedule:
 
     # ------------------------------------------------------------------ GEMM tile autotuning
     _tile_cache: Dict[tuple, int] = {}
+    _TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128), 5: (256, 256), 6: (256, 128), 7: (256, 128),
+                  8: (256, 128), 9: (128, 128)}
 
     @staticmethod
     def _gemm_key(f):
@@ -151,8 +153,15 @@ class Schedule:
                 key = self._gemm_key(f)
                 if key not in cache:
                     best, best_t = (0, 0), float("inf")
+                    M_, N_, K_ = key[:3]
                     for h in candidates:
-                        for sk in (0, 1):  # 0 = library heuristic, 1 = no split
+                        bm, bn = self._TILE_DIMS[h]
+                        tiles = -(-M_ // bm) * -(-N_ // bn) * key[3]
+                        # 0 = library heuristic, 1 = no split, explicit factors where the grid leaves CUs idle and K is deep
+                        sks = (0, 1) + (tuple(x for x in (2, 3, 4, 6, 8, 12)
+                                              if x * 8 <= K_ // 64 and tiles * x <= 1024 and x * key[3] * M_ * N_ <= 16 * 2 ** 20)
+                                        if tiles < 256 and not os.environ.get("VNETI_AUTOTUNE_NARROW") else ())
+                        for sk in sks:
                             kw = dict(f.keywords)
                             kw["tile_hint"], kw["split_k"] = h, sk
                             ops.gemm(*f.args, **kw)
