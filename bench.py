@@ -233,12 +233,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local)
+    # (debug aid: VNETI_DIST_BACKEND=gloo lets N ranks share one GPU to exercise the N > 1 control flow on a 1-GPU box)
+    backend = os.environ.get("VNETI_DIST_BACKEND", "nccl")
+    dev_index = local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     cfg, eng = build_engine(args, rank, world)
     if not args.no_graph:
