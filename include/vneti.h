@@ -70,7 +70,8 @@ typedef struct vneti_gemm_desc {
   long long ldx;
   int tile_hint;      /* 0 = heuristic; 1: 128x128, 2: 128x64, 3: 64x64, 4: 256x128 (8 waves), 5: 256x256 (16 waves, f16 out),
                          6: 256x128 with a 3-stage LDS ring and cross-barrier fragment prefetch,
-                         7: the same ring with 16 waves (64x32 wave tiles), 8: 256x128 / 16 waves, 9: 128x128 / 8 waves;
+                         7: the same ring with 16 waves (64x32 wave tiles), 8: 256x128 / 16 waves, 9: 128x128 / 8 waves,
+                         10 / 11 / 12: the 3-stage ring on 128x128 (8 waves) / 128x64 / 64x64 (under-filled grids: 2 stages in flight);
                          +100 selects the register-staged (non LDS-DMA) reference variant */
   /* split-K: f32 partials go to `workspace` (>= split_k*batch*M*N*4 bytes) and a second kernel
      reduces them and applies the epilogue.  split_k 0 = heuristic (only if a workspace is given),

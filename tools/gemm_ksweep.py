@@ -5,7 +5,7 @@ import torch
 from view_neti_amd import ops
 
 dev = "cuda"
-TILES = {10: (256, 256), 11: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128), 5: (256, 256), 6: (256, 128), 7: (256, 128), 8: (256, 128), 9: (128, 128)}
+TILES = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128), 5: (256, 256), 6: (256, 128), 7: (256, 128), 8: (256, 128), 9: (128, 128), 10: (128, 128), 11: (128, 64), 12: (64, 64)}
 M = int(os.environ.get("M", 65536)); N = int(os.environ.get("N", 256))
 for hint in [int(x) for x in os.environ.get("HINTS", "5,4,7,8,1,9,2,3").split(",")]:
     bm, bn = TILES[hint]

@@ -663,8 +663,8 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
 struct TileDims {
   int bm, bn;
 };
-constexpr TileDims kTiles[10] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128},
-                                {256, 256}, {256, 128}, {256, 128}, {256, 128}, {128, 128}};
+constexpr TileDims kTiles[13] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128}, {256, 256}, {256, 128},
+                                {256, 128}, {256, 128}, {128, 128}, {128, 128}, {128, 64},  {64, 64}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -699,7 +699,7 @@ extern "C" int vneti_gemm_select_split(int M, int N, int K, int batch, int tile_
   if (batch <= 0) batch = 1;
   int cfg = tile_hint >= 100 ? tile_hint - 100 : tile_hint;
   if (cfg == 0) cfg = select_tile(M, N, batch);
-  if (cfg < 1 || cfg > 9 || K % 64 != 0) return -1;
+  if (cfg < 1 || cfg > 12 || K % 64 != 0) return -1;
   int ks = select_ksplit(M, N, K, batch, cfg, workspace_bytes / 4);
   const int nk = K / 64;
   if (ks > nk) ks = nk;
@@ -807,9 +807,10 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     cfg -= 100;
   }
   if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
-  VN_REQUIRE(cfg >= 1 && cfg <= 9, "gemm: unknown tile_hint %d", d->tile_hint);
+  VN_REQUIRE(cfg >= 1 && cfg <= 12, "gemm: unknown tile_hint %d", d->tile_hint);
   if (cfg == 5 && f32) cfg = 4;  // the 256x256 tile's f32 epilogue staging would not fit in LDS
   if ((cfg == 6 || cfg == 7) && !dma) cfg = 4;  // the 3-stage ring exists with LDS-DMA only
+  if (cfg >= 10 && !dma) cfg = kTiles[cfg].bm == 128 ? (kTiles[cfg].bn == 128 ? 1 : 2) : 3;
   long long ws_floats = d->workspace ? d->workspace_bytes / 4 : 0;
   int ks = d->split_k;
   if (ks == 0) ks = select_ksplit(d->M, d->N, d->K, batch, cfg, ws_floats);
@@ -838,6 +839,10 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     case 7: return launch_cfg_ring<256, 128, 64, 32>(g, f32, st);  // 16 waves x (64x32), 3-stage ring
     case 8: LAUNCH(256, 128, 64, 32);                              // 16 waves x (64x32)
     case 9: LAUNCH(128, 128, 64, 32);                              // 8 waves x (64x32)
+    // 3-stage rings of the small tiles: two stages in flight for the fill-bound shapes
+    case 10: return launch_cfg_ring<128, 128, 64, 32>(g, f32, st);
+    case 11: return launch_cfg_ring<128, 64, 64, 32>(g, f32, st);
+    case 12: return launch_cfg_ring<64, 64, 32, 32>(g, f32, st);
     default:
       return dma ? launch_cfg_f16<256, 256, 64, 64, true>(g, st) : launch_cfg_f16<256, 256, 64, 64, false>(g, st);
   }

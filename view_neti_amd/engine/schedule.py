@@ -121,7 +121,7 @@ class Schedule:
     # ------------------------------------------------------------------ GEMM tile autotuning
     _tile_cache: Dict[tuple, int] = {}
     _TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128), 5: (256, 256), 6: (256, 128), 7: (256, 128),
-                  8: (256, 128), 9: (128, 128)}
+                  8: (256, 128), 9: (128, 128), 10: (128, 128), 11: (128, 64), 12: (64, 64)}
 
     @staticmethod
     def _gemm_key(f):
@@ -134,7 +134,7 @@ class Schedule:
         ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
         return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32)
 
-    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9), reps=8):
+    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12), reps=8):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
         tile configuration, with the split-K heuristic and with split-K forced off (the f32 partials
         and the reduce launch are not always worth the extra blocks), and pin the fastest pair.  Launches are
@@ -145,6 +145,8 @@ class Schedule:
             return
         import os
         cold = None if os.environ.get("VNETI_AUTOTUNE_HOT") else torch.empty(160 * 2 ** 20, dtype=torch.float32, device=self.dev)
+        if os.environ.get("VNETI_AUTOTUNE_CANDS"):
+            candidates = tuple(int(x) for x in os.environ["VNETI_AUTOTUNE_CANDS"].split(","))
         cache = Schedule._tile_cache
         for lst in (self.fwd_pre, self.fwd, self.bwd):
             for idx, f in enumerate(lst):
@@ -160,7 +162,7 @@ class Schedule:
                         # 0 = library heuristic, 1 = no split, explicit factors where the grid leaves CUs idle and K is deep
                         sks = (0, 1) + (tuple(x for x in (2, 3, 4, 6, 8, 12)
                                               if x * 8 <= K_ // 64 and tiles * x <= 1024 and x * key[3] * M_ * N_ <= 16 * 2 ** 20)
-                                        if tiles < 256 and not os.environ.get("VNETI_AUTOTUNE_NARROW") else ())
+                                        if tiles < 256 else ())
                         for sk in sks:
                             kw = dict(f.keywords)
                             kw["tile_hint"], kw["split_k"] = h, sk
