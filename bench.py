@@ -121,7 +121,9 @@ def pmc_traffic(tile_name: str):
     if not files:
         return {"traffic": None}
     dims = re.findall(r"\d+", tile_name.split(",ring")[0])
-    pats = ["gemm_kernel<" + ", ".join(dims) + ", false", "gemm_kernelILi" + "ELi".join(dims) + "ELb0E"]
+    stages = "3" if ",ring3" in tile_name else "2"
+    pats = ["gemm_kernel<" + ", ".join(dims) + ", false, true, " + stages + ">",
+            "gemm_kernelILi" + "ELi".join(dims) + "ELb0ELb1ELi" + stages + "E"]
     try:
         ks = json.load(open(files[-1]))["kernels"]
     except (OSError, ValueError, KeyError):
