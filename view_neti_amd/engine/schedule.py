@@ -148,6 +148,15 @@ class Schedule:
         if os.environ.get("VNETI_AUTOTUNE_CANDS"):
             candidates = tuple(int(x) for x in os.environ["VNETI_AUTOTUNE_CANDS"].split(","))
         cache = Schedule._tile_cache
+        # optional on-disk cache of the picks (profiling runs reuse a previous run's picks so that the rocprofv3
+        # per-kernel averages are those of the step, not of the autotuner's probes)
+        cache_path = os.environ.get("VNETI_AUTOTUNE_CACHE")
+        if cache_path and os.path.exists(cache_path) and not cache:
+            import ast
+            import json
+            for k, v in json.load(open(cache_path)).items():
+                cache[ast.literal_eval(k)] = tuple(v)  # keys: repr() of tuples of ints / None / bools written below
+        n_before = len(cache)
         for lst in (self.fwd_pre, self.fwd, self.bwd):
             for idx, f in enumerate(lst):
                 if getattr(f, "func", None) is not ops.gemm or f.keywords.get("tile_hint"):
@@ -194,6 +203,9 @@ class Schedule:
                 kw = dict(f.keywords)
                 kw["tile_hint"], kw["split_k"] = cache[key]
                 lst[idx] = self._rebound(f, ops.gemm, kw)
+        if cache_path and len(cache) != n_before:
+            import json
+            json.dump({repr(k): list(v) for k, v in cache.items()}, open(cache_path, "w"))
 
     def bind_workspace(self):
         """pin this schedule's own split-K / q-split scratch into every launch that may use one."""
