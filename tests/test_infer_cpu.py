@@ -98,3 +98,24 @@ def test_prompt_manager_contract():
     assert plain.view_params is None
     with pytest.raises(AssertionError):
         pm.embed_prompt("<view_a> <view_b> a <toy>")  # two tokens of one kind (prompt_manager.py:62-64)
+
+
+def test_rotation_coefficients_reproduce_pillow_rotate():
+    """host half of the device-side RandomRotation (engine/input_pipeline.py::rotation_coefficients): the six 16.16
+    integers, run through a numpy restatement of Geometry.c affine_fixed, reproduce Image.rotate bit for bit"""
+    import numpy as np
+    from PIL import Image
+    from view_neti_amd.engine.input_pipeline import rotation_coefficients
+    rng = np.random.default_rng(0)
+    for (h, w) in ((48, 64), (64, 64), (37, 53)):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for angle in (-10.0, -3.3, 0.7, 9.99, 45.0):
+            a0, a1, a2, a3, a4, a5 = rotation_coefficients(angle, w, h)
+            ys, xs = np.mgrid[0:h, 0:w]
+            xin = (a2 + ys * a1 + xs * a0) >> 16
+            yin = (a5 + ys * a4 + xs * a3) >> 16
+            ok = (xin >= 0) & (xin < w) & (yin >= 0) & (yin < h)
+            out = np.full((h, w, 3), 1, np.uint8)
+            out[ok] = a[yin[ok], xin[ok]]
+            ref = np.asarray(Image.fromarray(a).rotate(angle, resample=Image.NEAREST, expand=False, fillcolor=(1, 1, 1)))
+            assert np.array_equal(out, ref), (h, w, angle)

@@ -166,7 +166,7 @@ class Schedule:
                     best, best_t = (0, 0), float("inf")
                     M_, N_, K_ = key[:3]
                     for h in candidates:
-                        bm, bn = self._TILE_DIMS[h]
+                        bm, bn = self._TILE_DIMS[h % 100]
                         tiles = -(-M_ // bm) * -(-N_ // bn) * key[3]
                         # 0 = library heuristic, 1 = no split, explicit factors where the grid leaves CUs idle and K is deep
                         sks = (0, 1) + (tuple(x for x in (2, 3, 4, 6, 8, 12)
