@@ -62,19 +62,16 @@ def dtu_get_gt_images(cam_idxs, train_data_dir, dtu_lighting, dtu_preprocess_key
 
 
 def get_object_masks(cam_idxs, scan_idx, dtu_preprocess_key=1, masks_root=DTU_MASKS) -> Dict[int, Image.Image]:
-    """inference_dtu.py:375-398: IDR object masks, all-white when a mask file is missing"""
-    out = {}
-    for cam_idx in cam_idxs:
-        dir_mask = Path(masks_root) / f"scan{scan_idx}/mask"
-        f_mask = (dir_mask / f"{cam_idx:03d}.png") if dir_mask.exists() else dir_mask.parent / f"{cam_idx:03d}.png"
-        try:
-            mask = Image.open(f_mask).convert("RGB")
-        except FileNotFoundError:
-            mask = Image.new("RGB", (1600, 1200), color=(255, 255, 255))
-        if dtu_preprocess_key == 1:
-            mask = mask.resize((400, 300))
-        out[cam_idx] = mask
-    return out
+    """inference_dtu.py:375-398: the IDR object masks (either `<root>/scanN/mask/NNN.png` or `<root>/scanN/NNN.png`);
+    a view without a mask file counts as fully foreground"""
+    scan_dir = Path(masks_root) / f"scan{scan_idx}"
+    folder = scan_dir / "mask" if (scan_dir / "mask").exists() else scan_dir
+    masks = {}
+    for cam in cam_idxs:
+        f = folder / f"{cam:03d}.png"
+        m = Image.open(f).convert("RGB") if f.exists() else Image.new("RGB", (1600, 1200), (255, 255, 255))
+        masks[cam] = m.resize((400, 300)) if dtu_preprocess_key == 1 else m
+    return masks
 
 
 # ---------------------------------------------------------------------------------------------- tensor helpers
@@ -107,41 +104,36 @@ def make_grid(t: torch.Tensor, nrow: int = 8, padding: int = 2, pad_value: float
     return grid
 
 
+def _stack_chw(lookup, cam_idxs) -> torch.Tensor:
+    """dict camidx -> HWC uint8 image(s)  ->  uint8 tensor with channels before the spatial axes"""
+    arr = np.stack([np.asarray(lookup[c]) for c in cam_idxs])
+    return torch.from_numpy(arr).movedim(-1, -3)
+
+
 def process_imgs(cam_idxs, cam_idxs_train, lookup_camidx_to_img_pred, lookup_camidx_to_img_gt, lookup_camidx_to_mask):
-    """inference_dtu.py:401-465: everything to (.., C, 300, 400) in [0, 1]; masks thresholded at 0.01"""
-    imgs_pred = np.stack([np.asarray(lookup_camidx_to_img_pred[i]) for i in cam_idxs])
-    assert imgs_pred.ndim == 5, "expected (bs,n_seeds,h,w,3)"
-    imgs_pred = torch.tensor(imgs_pred).permute(0, 1, 4, 2, 3)
-    imgs_gt = np.stack([np.asarray(lookup_camidx_to_img_gt[i]) for i in cam_idxs])
-    masks = np.stack([np.asarray(lookup_camidx_to_mask[i]) for i in cam_idxs])
-    assert imgs_gt.ndim == 4 and masks.ndim == 4, "expected (bs,h,w,3)"
-    imgs_gt = torch.tensor(imgs_gt).permute(0, 3, 1, 2)
-    masks = torch.tensor(masks).permute(0, 3, 1, 2)
-    h_pred, w_pred = imgs_pred.shape[-2:]
-    h_gt, w_gt = imgs_gt.shape[-2:]
-    assert h_gt / w_gt == h_pred / w_pred == 0.75
-    h_new, w_new = 300, 400
-    imgs_gt = resize_bicubic_uint8(imgs_gt, (h_new, w_new))
-    masks = resize_bicubic_uint8(masks, (h_new, w_new))
-    bs, n_seeds, c, h, w = imgs_pred.shape
-    imgs_pred = resize_bicubic_uint8(imgs_pred.reshape(bs * n_seeds, c, h, w), (h_new, w_new))
-    imgs_pred = imgs_pred.contiguous().view(bs, n_seeds, c, h_new, w_new)
-    plot = []
-    for i, cam_idx in enumerate(cam_idxs):
-        if cam_idx in cam_idxs_train:  # yellow header marks the training views
-            header = torch.ones((3, 50, w_new)) * torch.tensor([255, 255, 0])[:, None, None]
-        else:
-            header = torch.zeros((3, 50, w_new))
-        plot.append(torch.cat((header, imgs_gt[i]), dim=1).unsqueeze(0))
-    imgs_gt_plot = torch.cat(plot)
-    imgs_pred = imgs_pred / 255.0
-    imgs_gt = imgs_gt / 255.0
-    imgs_gt_plot = imgs_gt_plot / 255.0
-    masks = masks / 255.0
-    thresh = 0.01
-    masks[masks > thresh] = 1
-    masks[masks <= thresh] = 0
-    return imgs_pred, imgs_gt, masks, imgs_gt, imgs_gt_plot
+    """inference_dtu.py:401-465: predictions (views, seeds, C, H, W), ground truth and masks (views, C, H, W), all
+    brought to the 300 x 400 evaluation size in [0, 1]; masks binarised at 0.01; plus the ground truth with a 50-row
+    header (yellow on training views) for the figure.  Returns (pred, gt, masks, gt, gt_plot) like the reference."""
+    size = (300, 400)
+    pred = _stack_chw(lookup_camidx_to_img_pred, cam_idxs)
+    gt = _stack_chw(lookup_camidx_to_img_gt, cam_idxs)
+    mk = _stack_chw(lookup_camidx_to_mask, cam_idxs)
+    if pred.dim() != 5 or gt.dim() != 4 or mk.dim() != 4:
+        raise ValueError("expected predictions (views, seeds, h, w, 3) and ground truth / masks (views, h, w, 3)")
+    for t in (pred, gt):
+        if t.shape[-2] / t.shape[-1] != 0.75:
+            raise ValueError("the DTU evaluation assumes 3:4 images")
+    n_views, n_seeds = pred.shape[:2]
+    gt = resize_bicubic_uint8(gt, size)
+    mk = resize_bicubic_uint8(mk, size)
+    pred = resize_bicubic_uint8(pred.flatten(0, 1), size).unflatten(0, (n_views, n_seeds))
+    header = torch.zeros(n_views, 3, 50, size[1])
+    is_train = torch.tensor([c in cam_idxs_train for c in cam_idxs])
+    header[is_train] = torch.tensor([255.0, 255.0, 0.0]).view(1, 3, 1, 1)
+    gt_plot = torch.cat((header, gt.float()), dim=2) / 255.0
+    pred, gt = pred / 255.0, gt / 255.0
+    masks = (mk / 255.0 > 0.01).to(gt.dtype)
+    return pred, gt, masks, gt, gt_plot
 
 
 # ---------------------------------------------------------------------------------------------- metrics
