@@ -147,6 +147,7 @@ class Schedule:
         cold = None if os.environ.get("VNETI_AUTOTUNE_HOT") else torch.empty(160 * 2 ** 20, dtype=torch.float32, device=self.dev)
         if os.environ.get("VNETI_AUTOTUNE_CANDS"):
             candidates = tuple(int(x) for x in os.environ["VNETI_AUTOTUNE_CANDS"].split(","))
+        cold_reps = int(os.environ.get("VNETI_AUTOTUNE_REPS", "5"))
         cache = Schedule._tile_cache
         # optional on-disk cache of the picks (profiling runs reuse a previous run's picks so that the rocprofv3
         # per-kernel averages are those of the step, not of the autotuner's probes)
@@ -188,15 +189,16 @@ class Schedule:
                             else:
                                 # cold timing: inside the step a GEMM's operands were evicted by its predecessors;
                                 # a fill of a buffer larger than L2 + MALL between the timed launches restores that
-                                t = 0.0
-                                for _ in range(max(3, reps // 2)):
+                                ts = []
+                                for _ in range(cold_reps):
                                     cold.fill_(0)
                                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                                     s.record()
                                     ops.gemm(*f.args, **kw)
                                     e.record()
                                     e.synchronize()
-                                    t += s.elapsed_time(e)
+                                    ts.append(s.elapsed_time(e))
+                                t = sorted(ts)[len(ts) // 2]  # median: one slow outlier must not veto a candidate
                             if t < best_t:
                                 best, best_t = (h, sk), t
                     cache[key] = best
