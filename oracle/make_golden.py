@@ -77,6 +77,53 @@ def install_reference():
     sys.path.insert(0, REF)
 
 
+def install_transformers_4_27_shim():
+    """models/neti_clip_text_encoder.py:9,103,111 subclasses transformers-4.27 internals that transformers 5.x no
+    longer has.  Give the import what it asks for, built ON TOP OF the installed library's own layers (no reference
+    code involved): `_expand_mask`, a `CLIPTextTransformer` base whose only inherited member the reference uses is
+    `_build_causal_attention_mask` (4.27: finfo.min above the diagonal, shape (B,1,L,L)), and a `CLIPEncoder`
+    whose forward accepts the 4.27 keyword set and adds the causal mask to the padding mask before running the
+    installed CLIPEncoderLayer stack."""
+    import transformers.models.clip.modeling_clip as mc
+    from transformers.modeling_outputs import BaseModelOutput
+
+    if hasattr(mc, "CLIPTextTransformer"):
+        return
+
+    def _expand_mask(mask, dtype, tgt_len=None):
+        bsz, src_len = mask.size()
+        tgt_len = tgt_len if tgt_len is not None else src_len
+        inv = 1.0 - mask[:, None, None, :].expand(bsz, 1, tgt_len, src_len).to(dtype)
+        return inv.masked_fill(inv.to(torch.bool), torch.finfo(dtype).min)
+
+    class CLIPTextTransformer(torch.nn.Module):
+        def __init__(self, config):
+            super().__init__()
+
+        def _build_causal_attention_mask(self, bsz, seq_len, dtype):
+            mask = torch.empty(bsz, seq_len, seq_len, dtype=dtype)
+            mask.fill_(torch.tensor(torch.finfo(dtype).min))
+            mask.triu_(1)
+            return mask.unsqueeze(1)
+
+    base_encoder = mc.CLIPEncoder
+
+    class CLIPEncoder(base_encoder):
+        def forward(self, inputs_embeds, attention_mask=None, causal_attention_mask=None, output_attentions=None,
+                    output_hidden_states=None, return_dict=None, **kwargs):
+            mask = causal_attention_mask
+            if attention_mask is not None:
+                mask = attention_mask if mask is None else mask + attention_mask
+            h = inputs_embeds
+            for layer in self.layers:
+                h = layer(h, mask, **kwargs)
+            return BaseModelOutput(last_hidden_state=h, hidden_states=None, attentions=None)
+
+    mc._expand_mask = _expand_mask
+    mc.CLIPTextTransformer = CLIPTextTransformer
+    mc.CLIPEncoder = CLIPEncoder
+
+
 def save(name, **arrays):
     os.makedirs(OUT, exist_ok=True)
     conv = {}
@@ -96,6 +143,256 @@ def close(a, b, tol, what):
     ref = b.abs().max().item() + 1e-30
     assert err <= tol * max(1.0, ref), f"{what}: oracle vs reference max abs err {err} (ref max {ref})"
     print(f"  ok {what}: max abs err {err:.3e}")
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def synthetic_calibration(seed=11):
+    """a temp CWD holding 64 seeded 3x4 camera matrices where constants.py:13 expects the DTU calibration files"""
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            cal = os.path.join("data", "dtu", "Calibration", "cal18")
+            os.makedirs(cal)
+            rng = np.random.RandomState(seed)
+            mats = rng.randn(64, 3, 4) * np.array([[1e3, 1e3, 1e3, 1e5]])
+            for i in range(64):
+                np.savetxt(os.path.join(cal, f"pos_{i + 1:03d}.txt"), mats[i])
+            yield mats
+        finally:
+            os.chdir(cwd)
+
+
+def g_text_encoder_bypass(R, NeTIMapper, NeTIBatch, PESigmas):
+    """models/neti_clip_text_encoder.py:15-225 run for real (NeTICLIPTextModel(batch=NeTIBatch)) on a tiny CLIP
+    config with an object mapper and a dtu-12d view mapper, constrained and unconstrained bypass; the oracle's
+    neti_text_encoder must reproduce both returned hidden states."""
+    install_transformers_4_27_shim()
+    from transformers import CLIPTextConfig
+    from models.neti_clip_text_encoder import NeTICLIPTextModel
+    from training.dataset import TextualInversionDataset as TID
+    from view_neti_amd import sd_config as sc
+    Dh, V = 32, 96
+    tc = CLIPTextConfig(vocab_size=V, hidden_size=Dh, max_position_embeddings=77, num_hidden_layers=2,
+                        num_attention_heads=2, intermediate_size=64, hidden_act="quick_gelu")
+    tc._attn_implementation = "eager"
+    my_cfg = sc.CLIPTextConfig(vocab_size=V, hidden_size=Dh, num_layers=2, num_heads=2, intermediate_size=64,
+                               act="quick_gelu")
+    torch.manual_seed(21)
+    model = NeTICLIPTextModel(tc).eval()
+    tm = model.text_model
+    gen = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        for prm in tm.parameters():  # O(1) activations through the stack, informative LayerNorm affine
+            prm.copy_(torch.randn(prm.shape, generator=gen) * (0.25 if prm.dim() > 1 else 0.1))
+        for n, prm in tm.named_parameters():
+            if "layer_norm" in n and n.endswith("weight"):
+                prm.add_(1.0)
+    cw = {"text_model." + k: v.detach().clone() for k, v in tm.state_dict().items() if "position_ids" not in k}
+    obj_id, B = 90, 4
+    ids = torch.randint(0, 88, (B, 77), generator=torch.Generator().manual_seed(3))
+    pos_obj, pos_view = [5, 9, 2, 30], [7, 3, 11, 31]
+    arrays = {"cw." + k: v for k, v in cw.items()}
+    with synthetic_calibration() as mats:
+        toks, _ = TID.dtu_generate_dset_cam_tokens_params()
+        cams = [0, 8, 13, 22]
+        view_tokens = [toks[c] for c in cams]
+        view_ids = [91 + i for i in range(len(cams))]
+        for b in range(B):
+            ids[b, pos_obj[b]] = obj_id
+            ids[b, pos_view[b]] = view_ids[(b * 3) % 4]
+        ph_view = torch.tensor([view_ids[(b * 3) % 4] for b in range(B)])
+        t = torch.tensor([3, 700, 42, 999])
+        lay = torch.tensor([4, 4, 4, 4])
+        for tag, unc, with_view in (("obj", False, False), ("objview", False, True), ("objview_unc", True, True)):
+            torch.manual_seed(31)
+            mo = NeTIMapper(embedding_type="object", output_dim=Dh, arch_mlp_hidden_dims=64, use_nested_dropout=False,
+                            norm_scale=torch.tensor(0.4), pe_sigmas=PESigmas(sigma_t=0.03, sigma_l=2.0),
+                            output_bypass=True, arch_view_net=15, arch_view_disable_tl=False,
+                            bypass_unconstrained=unc, output_bypass_alpha=0.3).eval()
+            torch.manual_seed(32)
+            mv = NeTIMapper(embedding_type="view", output_dim=Dh, use_nested_dropout=False,
+                            norm_scale=torch.tensor(0.35),
+                            pe_sigmas=PESigmas(sigma_t=0.03, sigma_l=2.0, sigma_dtu12=0.5), output_bypass=True,
+                            placeholder_view_tokens=list(view_tokens), placeholder_view_token_ids=list(view_ids),
+                            arch_view_net=15, arch_view_disable_tl=False, bypass_unconstrained=unc,
+                            output_bypass_alpha=0.15).eval()
+            g2 = torch.Generator().manual_seed(33)
+            with torch.no_grad():
+                for m in (mo, mv):
+                    for n, prm in m.named_parameters():
+                        if n != "encoder.w":
+                            prm.add_(0.1 * torch.randn(prm.shape, generator=g2))
+            tm.embeddings.set_mapper({obj_id: mo}, mv if with_view else None, device="cpu")
+            batch = NeTIBatch(input_ids=ids.clone(), input_ids_placeholder_object=torch.full((B,), obj_id),
+                              input_ids_placeholder_view=ph_view.clone() if with_view else torch.full((B,), -1),
+                              timesteps=t, unet_layers=lay)
+            with torch.no_grad():
+                out, out_b = model(batch=batch)
+            last, last_b = out.last_hidden_state, out_b.last_hidden_state
+            sdo = {k: v.detach().clone() for k, v in mo.state_dict().items() if k != "encoder.w"}
+            sdv = {k: v.detach().clone() for k, v in mv.state_dict().items() if k != "encoder.w"}
+            params = torch.stack([mv.view_tokenid_2_view_params[i.item()] for i in ph_view]).float()
+            scaled = NeTIMapper.scale_m1_1(params, mv.cam_mins, mv.cam_maxs)
+            with torch.no_grad():
+                wo, bo = R.mapper_forward(sdo, R.fourier_w([0.03, 2.0]), t, lay, 0.4)
+                wv = bv = None
+                if with_view:
+                    wv, bv = R.mapper_forward(sdv, R.fourier_w([0.03, 2.0] + [0.5] * 12), t, lay, 0.35,
+                                              view_params=scaled)
+                m_last, m_b = R.neti_text_encoder(cw, my_cfg, ids, torch.full((B,), obj_id), wo, bo, unc, 0.3,
+                                                  ph_view if with_view else None, wv, bv, unc, 0.15)
+            close(m_last, last, 2e-5, f"G7 text encoder [{tag}] last_hidden_state")
+            close(m_b, last_b, 2e-5, f"G7 text encoder [{tag}] last_hidden_state_with_bypass")
+            assert (last - last_b).abs().max() > 1e-2
+            arrays.update({f"{tag}.last": last, f"{tag}.last_bypass": last_b, f"{tag}.pooled": out.pooler_output,
+                           f"{tag}.pooled_bypass": out_b.pooler_output})
+            if tag != "objview":  # same mapper weights in the two objview cases except the flag
+                arrays.update({f"{tag}.sdo.{k}": v for k, v in sdo.items()})
+            if tag == "objview":
+                arrays.update({f"objview.sdo.{k}": v for k, v in sdo.items()})
+                arrays.update({f"sdv.{k}": v for k, v in sdv.items()})
+                arrays.update(view_scaled=scaled)
+        # the plain input_ids= path of the same module (sd_pipeline_call.py:35-39 uses it for the negative prompt)
+        tm.embeddings.set_mapper({obj_id: mo}, None, device="cpu")
+        with torch.no_grad():
+            plain, none = model(input_ids=ids)
+        assert none is None
+        close(R.clip_plain(cw, my_cfg, ids), plain.last_hidden_state, 2e-5, "G7 text encoder plain input_ids path")
+        arrays.update(plain_last=plain.last_hidden_state)
+    save("g7_text_encoder_bypass", ids=ids, ph_view=ph_view, obj_id=np.array(obj_id), timesteps=t, layers=lay,
+         alpha_obj=np.array(0.3), alpha_view=np.array(0.15), norm_obj=np.array(0.4), norm_view=np.array(0.35), **arrays)
+
+
+def g6_config_dumps():
+    """training/config.py:11-293 run for real: RunConfig() and the three shipped train YAMLs decoded the way
+    pyrallis does (field-type coercion, nested dataclasses), then the post-`__post_init__` state dumped to plain
+    dicts.  The fixture keeps the raw YAML mapping (input) next to the dump (expected) so the CPU test needs no
+    reference file.  pyrallis is absent: the few lines below rebuild its decode over the REFERENCE dataclasses."""
+    import dataclasses
+    import json
+    import typing
+    from pathlib import Path
+    import yaml
+    import training.config as rc
+
+    def build(cls, d):
+        hints = typing.get_type_hints(cls)
+        kw = {}
+        for f in dataclasses.fields(cls):
+            if f.name not in d:
+                continue
+            v, tp = d[f.name], hints[f.name]
+            if dataclasses.is_dataclass(tp):
+                v = build(tp, v)
+            elif tp is Path or (typing.get_origin(tp) is typing.Union and Path in typing.get_args(tp) and
+                                str not in typing.get_args(tp)):
+                v = None if v is None else Path(v)
+            elif tp in (int, float) or (typing.get_origin(tp) is typing.Union and
+                                        set(typing.get_args(tp)) <= {int, float, type(None)}):
+                base = tp if tp in (int, float) else [a for a in typing.get_args(tp) if a is not type(None)][0]
+                v = None if v is None else base(v)
+            elif tp is str:  # pyrallis decodes by annotation: `dtu_lighting: 3` in a YAML becomes '3'
+                v = None if v is None else str(v)
+            kw[f.name] = v
+        return cls(**kw)
+
+    def plain(o):
+        if dataclasses.is_dataclass(o) and not isinstance(o, type):
+            return {f.name: plain(getattr(o, f.name)) for f in dataclasses.fields(o)}
+        if isinstance(o, Path):
+            return str(o)
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        if isinstance(o, type):  # utils/types.py:21-24 default typo `= float`
+            return None
+        return o
+
+    cases = {}
+    # the dataclass default of data.train_data_dir is a required field: give the one mandatory value
+    sources = {"default": {"data": {"train_data_dir": "data/x"}}}
+    for name in ("train", "train_m3", "train_m3_88scenes"):
+        with open(os.path.join(REF, "input_configs", name + ".yaml")) as f:
+            sources[name] = yaml.safe_load(f)
+    # exp-key switches (config.py:151-178) on top of train.yaml
+    for tag, over in (("train_keys_a", {"pe_sigma_exp_key": 4, "pe_t_exp_key": 2, "pe_l_exp_key": 1}),
+                      ("train_keys_b", {"pe_sigma_exp_key": 0, "pe_t_exp_key": 3})):
+        src = json.loads(json.dumps(sources["train"]))
+        src["model"].update(over)
+        sources[tag] = src
+    for name, src in sources.items():
+        src = json.loads(json.dumps(src))
+        rec = {"input": src}
+        try:
+            cfg = build(rc.RunConfig, src)
+            rec["dump"] = plain(cfg)
+        except (AssertionError, ValueError, TypeError) as e:
+            rec["raises"] = type(e).__name__
+            # the mode-3 YAMLs need the CLI-supplied super-category list (config.py:274): add it and dump that too
+            if src.get("learnable_mode") == 3 and not src["data"].get("super_category_object_tokens"):
+                src2 = json.loads(json.dumps(src))
+                if not src2["data"].get("placeholder_object_tokens"):  # train.yaml leaves these to the CLI as well
+                    src2["data"]["placeholder_object_tokens"] = list(
+                        src2.get("eval", {}).get("eval_placeholder_object_tokens") or ["<object>"])
+                n = len(src2["data"]["placeholder_object_tokens"])
+                src2["data"]["super_category_object_tokens"] = ["object"] * n
+                try:
+                    rec["input_completed"] = src2
+                    rec["dump_completed"] = plain(build(rc.RunConfig, src2))
+                except (AssertionError, ValueError, TypeError) as e2:
+                    rec["raises_completed"] = type(e2).__name__
+        cases[name] = rec
+        print(f"  G6 {name}: " + ("dump" if "dump" in rec else f"raises {rec['raises']}" +
+                                  (" (completed dump ok)" if "dump_completed" in rec else "")))
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, "g6_config_dumps.json")
+    with open(path, "w") as f:
+        json.dump(cases, f, indent=1, sort_keys=True)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def g7_dataset_statics():
+    """training/dataset.py:321-408,455-522 statics run for real: train-view splits, file-name <-> camera index,
+    lighting / index filters, token <-> parameter round trip, the calibration reader (on the synthetic files)."""
+    import json
+    from pathlib import Path
+    from training.dataset import TextualInversionDataset as TID
+    rec = {"train_idxs": {}}
+    for k in (0, 1, 3, 6, 9, -1, -2, -3):
+        rec["train_idxs"][str(k)] = list(TID.dtu_get_train_idxs(k))
+    try:
+        TID.dtu_get_train_idxs(2)
+        rec["train_idxs_2_raises"] = None
+    except NotImplementedError:
+        rec["train_idxs_2_raises"] = "NotImplementedError"
+    names = [TID.dtu_cam_and_lighting_to_fname(c, l) for c in (0, 7, 24, 48) for l in ("3", "max")]
+    rec["fnames"] = names
+    rec["cam_info"] = [list(TID.dtu_cam_info_from_fname(Path("x") / n)) for n in names]
+    paths = [Path("scan1") / n for n in names]
+    rec["filter_lighting_3"] = [str(p) for p in TID.dtu_filter_fnames_lighting(paths, "3")]
+    rec["filter_idx"] = [str(p) for p in TID.dtu_filter_image_paths_from_idx(list(reversed(paths)), [24, 0, 48])]
+    with synthetic_calibration() as mats:
+        toks, params = TID.dtu_generate_dset_cam_tokens_params()
+        rec["calib"] = mats.tolist()
+        rec["tokens"] = {str(k): toks[k] for k in sorted(toks)}
+        rec["params"] = {str(k): params[k].flatten().tolist() for k in sorted(params)}
+        back = {}
+        for k in (0, 13, 63):
+            p, key = TID.dtu_token_to_cam_params(toks[k], cam_idx_as_int=True)
+            back[str(k)] = {"params": p.tolist(), "key": key}
+        rec["token_to_params"] = back
+        novel = torch.tensor(mats[5]).float() * 1.5
+        rec["novel_token"] = TID.dtu_cam_params_to_token(novel)
+        rec["novel_params"] = novel.flatten().tolist()
+    path = os.path.join(OUT, "g7_dataset_statics.json")
+    with open(path, "w") as f:
+        json.dump(rec, f)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
 def main():
@@ -204,8 +501,7 @@ def main():
                  tokens=np.array(view_tokens), cam_mins=mv.cam_mins, cam_maxs=mv.cam_maxs, t=t, l=l, ids=ids,
                  params=params, scaled=scaled, word=out.word_embedding, bypass=out.bypass_output,
                  token0_params=p0, token0_key=np.array(key0),
-                 **{"sd." + k: v for k, v in sdv.items() if "output_layer" not in k},
-                 out_w=sdv["output_layer.0.weight"][:, :8], out_b=sdv["output_layer.0.bias"])
+                 **{"sd." + k: v for k, v in sdv.items()})
         finally:
             os.chdir(cwd)
 
@@ -342,6 +638,13 @@ def main():
     back = [string_to_num(s) for s in strs4]
     save("g8_helpers", xs=xs, scaled=s1, nums=np.array(nums), strs2=np.array(strs2), strs4=np.array(strs4),
          back=np.array(back))
+
+    # ---------------- G6 (config post-init dumps) and G7 (dataset statics) ---------------------------------
+    g6_config_dumps()
+    g7_dataset_statics()
+
+    # ---------------- G7 (text encoder): the real NeTICLIPTextModel incl. the bypass injection ------------------
+    g_text_encoder_bypass(R, NeTIMapper, NeTIBatch, PESigmas)
     print("all fixtures written and cross-checked against oracle/sd_ref.py")
 
 

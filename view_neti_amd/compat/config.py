@@ -67,9 +67,10 @@ class DataConfig:
     augmentation_key: int = 0
     # extension (not in the reference): run resize / flip / augmentations as HIP kernels on images cached in HBM
     # (engine/input_pipeline.py); same random draws, same pixels as the host path
-    device_input_pipeline: bool = False
-    # filled at run time (a plain class attribute in the reference, config.py:64)
-    placeholder_view_tokens: Optional[List[str]] = None
+    device_input_pipeline: bool = field(default=False, metadata={"ext": True})
+    # filled at run time; a plain class attribute (NOT a dataclass field) as in the reference (config.py:64), so it
+    # never enters config.yaml / the checkpoint's cfg dict
+    placeholder_view_tokens = None
 
     def __post_init__(self):
         # annotated `str` with an int default in the reference (config.py:66); file-name matching needs str
@@ -115,6 +116,10 @@ class ModelConfig:
     bypass_unconstrained_view: bool = False
     output_bypass_alpha_view: float = 0.2
     output_bypass_alpha_object: float = 0.2
+    # extension: hub ids such as the reference default "CompVis/stable-diffusion-v1-4" cannot be resolved offline.
+    # Training on SD-shaped SYNTHETIC weights must be asked for explicitly (benchmarks, tests); otherwise a
+    # non-local `pretrained_model_name_or_path` is an error (compat/sd_weights.py)
+    allow_synthetic_weights: bool = field(default=False, metadata={"ext": True})
 
     def __post_init__(self):
         # config.py:142-178 — the YAML sigma values are overridden by the *_exp_key switches (App. C Q3)
@@ -146,7 +151,8 @@ class EvalConfig:
     num_denoising_steps: int = 30
     dtu_upsample_key: int = 1
     eval_placeholder_object_tokens: List[str] = None
-    validation_view_tokens: Optional[List[str]] = None
+    # plain class attribute in the reference too (config.py:188)
+    validation_view_tokens = None
 
     def __post_init__(self):
         if self.validation_seeds is None:
@@ -206,18 +212,33 @@ class RunConfig:
 # ----------------------------------------------------------------------------------------------
 # mini-pyrallis
 # ----------------------------------------------------------------------------------------------
-def encode(obj):
+def encode(obj, include_ext: bool = True):
     """pyrallis.encode: dataclass -> plain dict (Path -> str), used for config.yaml and inside checkpoints
-    (training/logger.py:25-28, checkpoint_handler.py:59,64)."""
+    (training/logger.py:25-28, checkpoint_handler.py:59,64).  `include_ext=False` leaves out the fields this repo
+    adds to the reference's schema (metadata ext=True): the reference's `pyrallis.decode(RunConfig, ckpt['cfg'])`
+    (checkpoint_handler.py:142) rejects keys it does not know."""
     if is_dataclass(obj) and not isinstance(obj, type):
-        return {f.name: encode(getattr(obj, f.name)) for f in fields(obj)}
+        return {f.name: encode(getattr(obj, f.name), include_ext) for f in fields(obj)
+                if include_ext or not f.metadata.get("ext")}
     if isinstance(obj, Path):
         return str(obj)
     if isinstance(obj, dict):
-        return {k: encode(v) for k, v in obj.items()}
+        return {k: encode(v, include_ext) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
-        return [encode(v) for v in obj]
+        return [encode(v, include_ext) for v in obj]
     return obj
+
+
+def ext_fields(obj) -> Dict[str, Any]:
+    """{"section.field": value} of the extension fields (stored beside, not inside, a checkpoint's cfg)."""
+    out = {}
+    for f in fields(obj):
+        v = getattr(obj, f.name)
+        if is_dataclass(v):
+            out.update({f"{f.name}.{k}": x for k, x in ext_fields(v).items()})
+        elif f.metadata.get("ext"):
+            out[f.name] = v
+    return out
 
 
 def _coerce(tp, val):
@@ -256,8 +277,13 @@ def _coerce(tp, val):
 
 
 def decode(cls, d: Dict[str, Any]):
-    """pyrallis.decode: plain dict -> dataclass (checkpoint_handler.py:142)."""
+    """pyrallis.decode: plain dict -> dataclass (checkpoint_handler.py:142).  Unknown keys are an error, as with
+    pyrallis (a typo in a YAML file or a dotted override must not be dropped silently)."""
     hints = typing.get_type_hints(cls)
+    names = {f.name for f in fields(cls)}
+    unknown = sorted(set(d) - names)
+    if unknown:
+        raise ValueError(f"{cls.__name__}: unknown configuration key(s) {unknown}")
     kwargs = {}
     for f in fields(cls):
         if f.name in d:
