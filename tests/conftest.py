@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the test-suite trains on SD-shaped synthetic weights on purpose (no checkpoints exist offline); product code
+# refuses that unless asked (compat/sd_weights.py)
+os.environ.setdefault("VNETI_ALLOW_SYNTHETIC_WEIGHTS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu via gpurun)")
 

@@ -175,7 +175,10 @@ def test_mapper_module_and_checkpoint_format(tmp_path):
     emb = torch.load(tmp_path / "learned_embeds-steps-5.bin")
     assert list(emb) == ["<toy>"] and torch.equal(emb["<toy>"], E[49408])
     ck = torch.load(tmp_path / "mapper-steps-5_object.pt", weights_only=False)
-    assert set(ck) == {"cfg", "mappers"} and list(ck["mappers"]) == [49408]
+    # the reference's layout + one extra top-level key its loader never reads (extension fields, synthetic marker)
+    assert set(ck) == {"cfg", "mappers", "vneti_ext"} and list(ck["mappers"]) == [49408]
+    assert ck["vneti_ext"]["synthetic_sd_weights"] is False
+    assert "device_input_pipeline" not in ck["cfg"]["data"] and "allow_synthetic_weights" not in ck["cfg"]["model"]
     entry = ck["mappers"][49408]
     assert set(entry) == {"state_dict", "encoder", "placeholder_object_token"} and entry["placeholder_object_token"] == "<toy>"
     assert list(entry["state_dict"]) == ["net.0.weight", "net.0.bias", "net.1.weight", "net.1.bias", "net.3.weight",
@@ -187,3 +190,56 @@ def test_mapper_module_and_checkpoint_format(tmp_path):
     assert cfg2.model.target_norm_object == 0.4
     w2, _ = lookup[49408](torch.tensor([10, 500]), torch.tensor([0, 7]))
     assert torch.allclose(w, w2)
+
+
+def test_lr_schedules():
+    """compat/lr_schedule.py against the defining properties of diffusers' get_scheduler shapes (coach.py:759-770):
+    warm-up ramps linearly from 0, constant stays 1, linear/cosine/polynomial end at ~0 at num_training_steps, the
+    scheduler advances `world` ticks per optimizer step (accelerate's AcceleratedScheduler) with totals x accum."""
+    import math
+    from view_neti_amd.compat.lr_schedule import LRSchedule, lr_lambda
+    assert all(lr_lambda("constant", s, 10, 100) == 1.0 for s in (0, 5, 100, 1000))
+    assert lr_lambda("constant_with_warmup", 0, 10, 100) == 0.0 and lr_lambda("constant_with_warmup", 5, 10, 100) == 0.5
+    assert lr_lambda("constant_with_warmup", 10, 10, 100) == 1.0
+    assert lr_lambda("linear", 5, 10, 110) == 0.5 and lr_lambda("linear", 10, 10, 110) == 1.0
+    assert abs(lr_lambda("linear", 60, 10, 110) - 0.5) < 1e-12 and lr_lambda("linear", 110, 10, 110) == 0.0
+    assert abs(lr_lambda("cosine", 60, 10, 110) - 0.5) < 1e-12 and lr_lambda("cosine", 110, 10, 110) < 1e-12
+    assert abs(lr_lambda("cosine", 35, 10, 110) - 0.5 * (1 + math.cos(math.pi * 0.25))) < 1e-12
+    assert lr_lambda("cosine_with_restarts", 110, 10, 110) == 0.0 and lr_lambda("cosine_with_restarts", 10, 10, 110) == 1.0
+    assert abs(lr_lambda("polynomial", 110, 10, 110, lr_init=1e-3) - 1e-7 / 1e-3) < 1e-12
+    assert abs(lr_lambda("polynomial", 60, 10, 110, lr_init=1e-3) - (0.5 * (1e-3 - 1e-7) + 1e-7) / 1e-3) < 1e-12
+    with pytest.raises(ValueError):
+        lr_lambda("nope", 0, 0, 1)
+    s = LRSchedule("linear", 4e-3, lr_warmup_steps=2, max_train_steps=10, grad_accum=3, world=2)
+    assert s.warmup == 6 and s.total == 30 and not s.constant
+    assert s.lr(0) == 0.0 and abs(s.lr(3) - 4e-3) < 1e-15          # 3 optimizer steps x 2 ranks = 6 ticks = end of warm-up
+    assert abs(s.lr(9) - 4e-3 * (30 - 18) / 24) < 1e-15
+    assert LRSchedule("constant", 1e-3, 0, 10, 1, 8).constant
+
+
+def test_synthetic_weights_must_be_asked_for(monkeypatch):
+    """a hub id such as the reference default cannot be resolved offline — that is an error, not a silent
+    fall-back to random weights; the opt-in is explicit (config flag or environment)."""
+    from view_neti_amd import sd_config as sc
+    from view_neti_amd.compat import sd_weights
+    monkeypatch.delenv("VNETI_ALLOW_SYNTHETIC_WEIGHTS", raising=False)
+    with pytest.raises(FileNotFoundError, match="allow_synthetic_weights"):
+        sd_weights.load_sd_weights(sc.tiny(), "CompVis/stable-diffusion-v1-4", device="cpu")
+    with pytest.raises(FileNotFoundError):
+        sd_weights.load_vae_decoder_weights(sc.tiny(), "CompVis/stable-diffusion-v1-4", device="cpu")
+    assert sd_weights.synthetic_allowed(True)
+    monkeypatch.setenv("VNETI_ALLOW_SYNTHETIC_WEIGHTS", "1")
+    assert sd_weights.synthetic_allowed(False)
+
+
+def test_config_rejects_unknown_keys_and_keeps_ext_out_of_checkpoints():
+    from view_neti_amd.compat import config as C
+    with pytest.raises(ValueError, match="unknown configuration key"):
+        C.parse(C.RunConfig, ["--optim.learning_rat", "1e-3"])
+    cfg = C.parse(C.RunConfig, ["--data.device_input_pipeline", "true", "--model.allow_synthetic_weights", "true"])
+    full, ref = C.encode(cfg), C.encode(cfg, include_ext=False)
+    assert full["data"]["device_input_pipeline"] is True and "device_input_pipeline" not in ref["data"]
+    assert "allow_synthetic_weights" not in ref["model"] and "placeholder_view_tokens" not in ref["data"]
+    assert C.ext_fields(cfg) == {"data.device_input_pipeline": True, "model.allow_synthetic_weights": True}
+    cfg.data.placeholder_view_tokens = ["<v>"]  # run-time attribute, never serialised (config.py:64 of the reference)
+    assert "placeholder_view_tokens" not in C.encode(cfg)["data"]

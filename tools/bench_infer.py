@@ -1,5 +1,7 @@
 """Dev tool: inference throughput (BASELINE.json config 5: learnable_mode 5 style single-view generation,
 SD-2.1 shapes, 768x768 fp16, 50 sampler steps).  Prints one JSON line (images/s and s/image)."""
+import os
+os.environ.setdefault("VNETI_ALLOW_SYNTHETIC_WEIGHTS", "1")  # dev tool: synthetic SD-shaped weights on purpose
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("VNETI_ALLOW_SYNTHETIC_WEIGHTS", "1")  # dev tool: synthetic SD-shaped weights on purpose
 import sys, os, time, tempfile
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch

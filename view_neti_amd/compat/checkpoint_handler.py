@@ -20,8 +20,10 @@ from .neti_modules import NeTIMapper
 
 class CheckpointHandler:
     def __init__(self, cfg, placeholder_view_tokens: List[str], placeholder_view_token_ids: List[int],
-                 placeholder_object_tokens: List[str], placeholder_object_token_ids: List[int], save_root: Path):
+                 placeholder_object_tokens: List[str], placeholder_object_token_ids: List[int], save_root: Path,
+                 synthetic_weights: bool = False):
         self.cfg = cfg
+        self.synthetic_weights = synthetic_weights
         self.placeholder_tokens = list(placeholder_view_tokens) + list(placeholder_object_tokens)
         self.placeholder_token_ids = list(placeholder_view_token_ids) + list(placeholder_object_token_ids)
         self.save_root = Path(save_root)
@@ -36,16 +38,21 @@ class CheckpointHandler:
         torch.save({t: v.clone() for t, v in zip(self.placeholder_tokens, rows)}, self.save_root / save_name)
 
     def save_mapper(self, mapper_object_lookup, mapper_view, save_name: str):
-        enc_cfg = cfgmod.encode(self.cfg)
+        # "cfg" holds the reference's schema only (its pyrallis.decode rejects unknown keys, checkpoint_handler.py:142);
+        # this repo's extension fields and the synthetic-weights marker travel under a separate top-level key that the
+        # reference's loader never looks at
+        enc_cfg = cfgmod.encode(self.cfg, include_ext=False)
+        ext = {"config_ext": cfgmod.ext_fields(self.cfg), "synthetic_sd_weights": bool(self.synthetic_weights)}
         stem, suffix = Path(save_name).stem, Path(save_name).suffix
         if mapper_object_lookup is not None:
-            sd = {"cfg": enc_cfg, "mappers": {}}
+            sd = {"cfg": enc_cfg, "vneti_ext": ext, "mappers": {}}
             for token_id, m in mapper_object_lookup.items():
                 sd["mappers"][token_id] = {"state_dict": m.mapper_state(), "encoder": m.encoder,
                                            "placeholder_object_token": m.placeholder_object_token}
             torch.save(sd, os.path.join(self.save_root, stem + "_object" + suffix))
         if mapper_view is not None:
-            sd = {"cfg": enc_cfg, "mappers": {"dummy_key": {"state_dict": mapper_view.mapper_state(),
+            sd = {"cfg": enc_cfg, "vneti_ext": ext,
+                  "mappers": {"dummy_key": {"state_dict": mapper_view.mapper_state(),
                                                             "encoder": mapper_view.encoder,
                                                             "placeholder_object_token": "dummy"}}}
             torch.save(sd, os.path.join(self.save_root, stem + "_view" + suffix))

@@ -11,6 +11,7 @@ What is mirrored (file:line of the reference):
     mapper (device-side slot), a new scene is drawn after every optimizer step   coach.py:155-156, dataset.py:584-596
   * nested dropout / unconstrained bypass flags forwarded to the mappers   coach.py:525-584
   * lr = lr * accum * batch * world when scale_lr                         coach.py:727-733
+  * optim.lr_scheduler / lr_warmup_steps (compat/lr_schedule.py)          coach.py:759-770, :217
   * train loop, save every log.save_steps + final, file names            coach.py:137-274
   * validation images every eval.validation_steps (compat/validate.py: the live mappers on the inference engine;
     the DTU metric harness itself stays out of scope)                     coach.py:243-251, validate.py
@@ -33,6 +34,7 @@ from . import config as cfgmod
 from .checkpoint_handler import CheckpointHandler
 from .constants import UNET_LAYERS
 from .dataset import TextualInversionDataset
+from .lr_schedule import LRSchedule
 from .neti_modules import NeTIMapper
 from .sd_weights import load_sd_weights
 from .tokenizer import load_tokenizer
@@ -58,16 +60,25 @@ class Coach:
         if cfg.optim.seed is not None:
             torch.manual_seed(cfg.optim.seed)
         if cfg.optim.mixed_precision != "fp16":
-            self.log("NOTE: the HIP engine runs the frozen networks in fp16 (optim.mixed_precision='fp16' "
-                     "semantics) regardless of the configured value")
+            # the reference default is "no" (fp32 everywhere, config.py:241); that path does not exist here and
+            # running fp16 under a config that says otherwise would be a silent change of numerics
+            raise NotImplementedError(
+                f"optim.mixed_precision='{cfg.optim.mixed_precision}': the HIP engine implements the fp16 path only "
+                "(frozen UNet/VAE in f16, f32 statistics and accumulation, device GradScaler); pass "
+                "--optim.mixed_precision fp16")
+        if cfg.optim.gradient_checkpointing:
+            raise NotImplementedError("optim.gradient_checkpointing: the engine recomputes nothing (13.5 GiB at bs=4)")
         self.sd = _sd_family(cfg)
         self.tokenizer = load_tokenizer(str(cfg.model.pretrained_model_name_or_path), self.sd.clip.vocab_size)
         self.train_dataset = self._init_dataset()
         self._add_concept_tokens()
-        unet_w, vae_w, clip_w, synthetic = load_sd_weights(self.sd, str(cfg.model.pretrained_model_name_or_path), device)
+        unet_w, vae_w, clip_w, synthetic = load_sd_weights(self.sd, str(cfg.model.pretrained_model_name_or_path), device,
+                                                           allow_synthetic=cfg.model.allow_synthetic_weights)
+        self.synthetic_weights = synthetic
         if synthetic:
-            self.log(f"NOTE: '{cfg.model.pretrained_model_name_or_path}' is not a local checkpoint directory; using "
-                     "SD-shaped synthetic weights")
+            self.log(f"WARNING: '{cfg.model.pretrained_model_name_or_path}' is not a local checkpoint directory; "
+                     "training on SD-shaped SYNTHETIC weights (model.allow_synthetic_weights): checkpoints written by "
+                     "this run are marked synthetic")
         clip_w = self._extend_token_embedding(clip_w)
         self.mapper_object_lookup, self.mapper_view = self._init_neti_mappers()
         # engine slot k <-> k-th placeholder object token (mapper_object_lookup, coach.py:505-552)
@@ -78,11 +89,14 @@ class Coach:
         bs = cfg.optim.train_batch_size
         lr = parallel.scaled_lr(cfg.optim.learning_rate, cfg.optim.gradient_accumulation_steps, bs, self.world,
                                 cfg.optim.scale_lr)
+        self.lr_schedule = LRSchedule(cfg.optim.lr_scheduler, lr, cfg.optim.lr_warmup_steps, cfg.optim.max_train_steps,
+                                      cfg.optim.gradient_accumulation_steps, self.world)
         h, w = self._image_hw()
         kw = {}
         if self.mapper_view is not None:
+            # modes 4/5: the loaded mapper carries the alpha it was trained with (checkpoint_handler.py:163-169, Q8)
             kw = dict(mapper_view=self.mapper_view.mapper_state(), w_enc_view=self.mapper_view.encoder.w,
-                      norm_scale_view=self.mapper_view.norm_scale, alpha_view=cfg.model.output_bypass_alpha_view,
+                      norm_scale_view=self.mapper_view.norm_scale, alpha_view=self.mapper_view.output_bypass_alpha,
                       train_view=cfg.learnable_mode != 5)
         self.engine = TrainStepEngine(
             self.sd, unet_w, vae_w, clip_w, bs, h, w, [o.mapper_state() for o in objs], first.encoder.w,
@@ -92,17 +106,20 @@ class Coach:
             grad_accum=cfg.optim.gradient_accumulation_steps, hidden_object=first.hidden,
             unconstrained_object=m.bypass_unconstrained_object, unconstrained_view=m.bypass_unconstrained_view,
             nested_dropout_prob=m.nested_dropout_prob if m.use_nested_dropout else 0.0, **kw)
+        self.engine.set_lr(self.lr_schedule.lr(0))
         self.validator = None
         if cfg.eval.validation_prompts is not None and cfg.eval.validation_steps <= cfg.optim.max_train_steps \
                 and self.rank == 0:
             from .sd_weights import load_vae_decoder_weights
             from .validate import ValidationHandler
-            dec_w, _ = load_vae_decoder_weights(self.sd, str(cfg.model.pretrained_model_name_or_path), device)
+            dec_w, _ = load_vae_decoder_weights(self.sd, str(cfg.model.pretrained_model_name_or_path), device,
+                                                allow_synthetic=cfg.model.allow_synthetic_weights)
             self.validator = ValidationHandler(self, unet_w, dec_w, clip_w)
         del unet_w, vae_w, clip_w
         self.checkpoint_handler = CheckpointHandler(
             cfg, self.train_dataset.placeholder_view_tokens, self.placeholder_view_token_ids,
-            self.train_dataset.placeholder_object_tokens, self.placeholder_object_token_ids, cfg.log.exp_dir)
+            self.train_dataset.placeholder_object_tokens, self.placeholder_object_token_ids, cfg.log.exp_dir,
+            synthetic_weights=synthetic)
         # every rank draws its own batches (accelerate shards the prepared dataloader across processes,
         # coach.py:97-99): one shuffling stream per rank; rank 0 of a 1-process run keeps the global generator
         gen = None
@@ -152,9 +169,13 @@ class Coach:
             self.logger.info(msg)
 
     def _image_hw(self):
-        if "dtu" in str(self.cfg.data.train_data_dir) and self.cfg.learnable_mode != 0:
-            return {0: (512, 512), 1: (384, 512), 2: (576, 768)}[self.cfg.data.dtu_preprocess_key]
-        return self.cfg.data.resolution, self.cfg.data.resolution
+        """(H, W) of the tensors the dataset really produces (`_resize`, dataset.py:155-236): DTU roots give
+        384x512 / 576x768 frames in EVERY learnable mode, LLFF roots are not resized at all."""
+        hw = self.train_dataset.target_size()
+        if hw is None:
+            raise NotImplementedError("this data root is not resized by the dataset (llff): the engine needs one "
+                                      "static frame size")
+        return hw
 
     def _init_dataset(self):
         d = self.cfg.data
@@ -208,6 +229,9 @@ class Coach:
                                       "(set --model.arch_view_net 15 --model.arch_view_disable_tl False)")
         if m.original_ti:
             raise NotImplementedError("original_ti (plain textual inversion baseline) is outside the NeTI hot path")
+        if cfg.learnable_mode == 1:
+            raise NotImplementedError("learnable_mode 1 (view mapper only, fixed object word) is not built: the engine "
+                                      "always trains an object bucket; use mode 2, or mode 5 with a pretrained view mapper")
         if not (m.output_bypass_object and (m.output_bypass_view or cfg.learnable_mode == 0)):
             raise NotImplementedError("the HIP text path implements the paper's textual-bypass mappers "
                                       "(model.output_bypass_object / output_bypass_view = True)")
@@ -221,7 +245,7 @@ class Coach:
                                           use_nested_dropout=m.use_nested_dropout,
                                           nested_dropout_prob=m.nested_dropout_prob)
         view = None
-        if cfg.learnable_mode in (1, 2, 3):
+        if cfg.learnable_mode in (2, 3):
             ds = self.train_dataset
             cams = torch.stack(list(ds.lookup_camidx_to_cam_params.values()))
             view = NeTIMapper("view", m.word_embedding_dim, 64, m.target_norm_view, m.pe_sigmas, m.output_bypass_view,
@@ -297,6 +321,8 @@ class Coach:
                     self.train_dataset.reset_sampled_object()  # new scene only once the accumulation group is done
                 if stepped:
                     global_step += 1
+                    if not self.lr_schedule.constant:
+                        eng.set_lr(self.lr_schedule.lr(global_step))  # device scalar: no re-capture
                     if global_step % 50 == 0 or global_step == 1:
                         self.log(f"step {global_step} loss {eng.loss():.5f} lr {float(eng.hyper[0]):.2e} "
                                  f"{global_step / (time.time() - t0):.2f} it/s")

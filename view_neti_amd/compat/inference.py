@@ -64,8 +64,9 @@ def load_inference(exp_dir, mapper_stem: str = "mapper-final", batch: int = 1, h
             return (p - mins) / (maxs - mins) * 2 - 1
     object_token = object_token or object_tokens[0]
     mo = lookup[tok.convert_tokens_to_ids(object_token)]
-    unet_w, _, clip_w, synthetic = load_sd_weights(sd, str(cfg.model.pretrained_model_name_or_path), device)
-    dec_w, _ = load_vae_decoder_weights(sd, str(cfg.model.pretrained_model_name_or_path), device)
+    allow = cfg.model.allow_synthetic_weights
+    unet_w, _, clip_w, synthetic = load_sd_weights(sd, str(cfg.model.pretrained_model_name_or_path), device, allow)
+    dec_w, _ = load_vae_decoder_weights(sd, str(cfg.model.pretrained_model_name_or_path), device, allow)
     # grow the token table like Coach._extend_token_embedding (rows are placeholders for the mapper outputs)
     key = "text_model.embeddings.token_embedding.weight"
     E = clip_w[key]

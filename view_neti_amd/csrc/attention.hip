@@ -11,9 +11,11 @@
 // lane owns one query column: row max / row sum are in-lane reductions plus one cross-half
 // shuffle.  The accumulator registers 8j..8j+7 of a lane are then *directly* the B operand
 // (k = 8 keys) of the second MFMA  O^T[d][q] += V^T[d][key] . P^T[key][q]  if the A operand
-// is gathered with the same key order, which needs V^T (d-major) in LDS — callers supply the
-// per-batch transposed copies (vneti_transpose_f16).  Head dims 40/80 are zero padded to the
-// MFMA k-step (16) for contractions over d and to 32 for output rows.
+// is gathered with the same key order.  That A operand (V^T here; K^T, Q^T, dO^T in the backward
+// kernels) is read TRANSPOSED out of the row-major [key][d] LDS tile with ds_read_b64_tr_b16
+// (load_tr below): callers pass plain row-major Q/K/V/dO views, no transposed copies exist.
+// Head dims 40/80 are zero padded to the MFMA k-step (16) for contractions over d and to 32 for
+// output rows.
 #include "common.h"
 #include "../../include/vneti.h"
 

@@ -104,6 +104,9 @@ class InferenceEngine:
         self.text = TextEngine(cfg.clip, clip_w, nl, batch, self.t_text, self.ctx_k, self.ctx_v, None, None, mo, None,
                                mv, None, n_view_params, False, device, need_backward=False)
         self.text.training = False
+        # masks exist from the start: set_truncation() then mutates them in place and a captured sampler graph
+        # (whose launches bake the mask pointer in) honours a truncation_idx set after the capture
+        self.text.ensure_masks()
         self.decoder = VAEDecoderEngine(cfg.vae, vae_dec_w, batch, self.h, self.w, device)
         shape = (batch, self.Lc, self.h, self.w)
         self.x = torch.zeros(shape, dtype=torch.float32, device=device)

@@ -128,6 +128,14 @@ class TextEngine(Schedule):
             else:
                 mask.fill_(1.0)  # eval: no dropout (truncation_idx is an inference-only knob)
 
+    def ensure_masks(self):
+        """allocate all-ones hidden masks where nested dropout is off, so that `set_truncation` only ever mutates
+        buffers IN PLACE: a sampler graph captured before the first truncated call then still reads the mask (a
+        lazily created tensor would leave the captured launches with a null mask pointer)."""
+        for name, m in (("hidden_mask_obj", self.mo), ("hidden_mask_view", self.mv)):
+            if m is not None and getattr(self, name) is None:
+                setattr(self, name, torch.ones((self.R, m.hidden), dtype=torch.float32, device=self.dev))
+
     def set_truncation(self, truncation_idx: Optional[int]):
         """inference-time truncation of the mapper's hidden vector (`truncation_idx`, neti_mapper.py:409-411):
         hidden[idx:] = 0 for every call; None restores the full vector."""

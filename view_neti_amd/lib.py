@@ -93,11 +93,6 @@ def check(rc: int, what: str = ""):
         raise RuntimeError(f"vneti call failed ({what}) rc={rc}: {last_error()}")
 
 
-def _conv(a):
-    """Convert python values to ctypes-friendly ones (None -> NULL pointer)."""
-    return a
-
-
 def call(name: str, *args):
     """Call `vneti_<name>` with positional args; pointers are ints/None, scalars by python type.
 
