@@ -395,6 +395,95 @@ def g7_dataset_statics():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+def f2_reference_checkpoints(R, NeTIMapper, PESigmas):
+    """SURVEY f2 / checkpoint_handler.py:34-97: mapper checkpoints and a learned-embeds file laid out exactly as the
+    reference's CheckpointHandler.save_model writes them, holding the REFERENCE's own objects: `state_dict()` of its
+    NeTIMapper and the pickled `models.positional_encoding.FourierPositionalEncodingNDims` instance.  (pyrallis is
+    absent, so `pyrallis.encode(cfg)` is the plain-dict dump of the reference RunConfig used for G6; the file is
+    assembled by hand in the documented layout.)  On a CUDA box `nn.Parameter(w).cuda()` leaves `encoder.w` a plain
+    tensor attribute outside state_dict (App. C Q2); the no-op `.cuda()` of this harness would register it, so it is
+    moved back to what a real run pickles."""
+    import dataclasses
+    from pathlib import Path
+    import yaml
+    import training.config as rc
+    from training.dataset import TextualInversionDataset as TID
+    D = 32
+
+    def as_cuda_run(m):
+        enc = m.encoder
+        if "w" in enc._parameters:
+            w = enc._parameters.pop("w").detach().clone()
+            enc.__dict__["w"] = w
+        return {k: v.detach().clone() for k, v in m.state_dict().items() if k != "encoder.w"}
+
+    def plain(o):
+        if dataclasses.is_dataclass(o) and not isinstance(o, type):
+            return {f.name: plain(getattr(o, f.name)) for f in dataclasses.fields(o)}
+        if isinstance(o, Path):
+            return str(o)
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        return None if isinstance(o, type) else o
+
+    with open(os.path.join(REF, "input_configs", "train_m3.yaml")) as f:
+        src = yaml.safe_load(f)
+    cfg = rc.RunConfig(
+        learnable_mode=2, log=rc.LogConfig(exp_name="f2", exp_dir=Path("results")),
+        data=rc.DataConfig(train_data_dir=Path("data/dtu/Rectified/scan114"), placeholder_object_token="<obj>",
+                           camera_representation="dtu-12d", dtu_subset=6, dataloader_num_workers=0),
+        model=rc.ModelConfig(word_embedding_dim=D, arch_mlp_hidden_dims=64, use_nested_dropout=False,
+                             normalize_view_mapper_output=True, arch_view_net=15, arch_view_disable_tl=False,
+                             pe_sigma_exp_key=2, output_bypass_alpha_view=5, output_bypass_alpha_object=5,
+                             pe_sigmas=dict(src["model"]["pe_sigmas"]), target_norm_object=0.4, target_norm_view=0.35))
+    enc_cfg = plain(cfg)
+    gen = torch.Generator().manual_seed(41)
+    t = torch.tensor([10.0, 500.0, 999.0, 3.0])
+    lay = torch.tensor([0.0, 7.0, 15.0, 2.0])
+    with synthetic_calibration() as mats:
+        toks, _ = TID.dtu_generate_dset_cam_tokens_params()
+        cams = [25, 22, 28, 40, 44, 48]
+        view_tokens, view_ids = [toks[c] for c in cams], [91 + i for i in range(len(cams))]
+        torch.manual_seed(42)
+        mo = NeTIMapper(embedding_type="object", output_dim=D, arch_mlp_hidden_dims=64, use_nested_dropout=False,
+                        norm_scale=torch.tensor(0.4), pe_sigmas=cfg.model.pe_sigmas, output_bypass=True,
+                        arch_view_net=15, arch_view_disable_tl=False, bypass_unconstrained=False,
+                        output_bypass_alpha=5, placeholder_object_token="<obj>").eval()
+        mv = NeTIMapper(embedding_type="view", output_dim=D, use_nested_dropout=False, norm_scale=torch.tensor(0.35),
+                        pe_sigmas=cfg.model.pe_sigmas, output_bypass=True, placeholder_view_tokens=list(view_tokens),
+                        placeholder_view_token_ids=list(view_ids), arch_view_net=15, arch_view_disable_tl=False,
+                        bypass_unconstrained=False, output_bypass_alpha=5).eval()
+        with torch.no_grad():
+            for m in (mo, mv):
+                for n, prm in m.named_parameters():
+                    if n != "encoder.w":
+                        prm.add_(0.1 * torch.randn(prm.shape, generator=gen))
+            ids = torch.tensor([view_ids[0], view_ids[3], view_ids[5], view_ids[1]])
+            out_o = mo(timestep=t, unet_layer=lay, input_ids_placeholder_view=None, truncation_idx=None)
+            out_v = mv(timestep=t, unet_layer=lay, input_ids_placeholder_view=ids, truncation_idx=None)
+            params = torch.stack([mv.view_tokenid_2_view_params[i.item()] for i in ids]).float()
+            scaled = NeTIMapper.scale_m1_1(params, mv.cam_mins, mv.cam_maxs)
+        sdo, sdv = as_cuda_run(mo), as_cuda_run(mv)
+        os.makedirs(OUT, exist_ok=True)
+        torch.save({"cfg": enc_cfg, "mappers": {90: {"state_dict": sdo, "encoder": mo.encoder,
+                                                    "placeholder_object_token": "<obj>"}}},
+                   os.path.join(OUT, "f2_mapper-steps-7_object.pt"))
+        torch.save({"cfg": enc_cfg, "mappers": {"dummy_key": {"state_dict": sdv, "encoder": mv.encoder,
+                                                              "placeholder_object_token": "dummy"}}},
+                   os.path.join(OUT, "f2_mapper-steps-7_view.pt"))
+        # learned_embeds-*.bin: {token: Tensor(D,) cpu fp32}, view tokens first, then object tokens (:40-55)
+        emb = {tok: torch.randn(D, generator=gen) for tok in view_tokens[:2] + ["<obj>"]}
+        torch.save(emb, os.path.join(OUT, "f2_learned_embeds-steps-7.bin"))
+        save("f2_expected", t=t, l=lay, word_obj=out_o.word_embedding, bypass_obj=out_o.bypass_output,
+             word_view=out_v.word_embedding, bypass_view=out_v.bypass_output, view_scaled=scaled, cam_mins=mv.cam_mins,
+             cam_maxs=mv.cam_maxs, emb_tokens=np.array(list(emb)), emb_values=torch.stack(list(emb.values())),
+             sigma_dtu12=np.array(cfg.model.pe_sigmas.sigma_dtu12), w_view=mv.encoder.w, w_obj=mo.encoder.w)
+    for f in ("f2_mapper-steps-7_object.pt", "f2_mapper-steps-7_view.pt", "f2_learned_embeds-steps-7.bin"):
+        print(f"wrote {os.path.join(OUT, f)} ({os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB)")
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference not mounted; fixtures can only be generated in the build container")
@@ -642,6 +731,9 @@ def main():
     # ---------------- G6 (config post-init dumps) and G7 (dataset statics) ---------------------------------
     g6_config_dumps()
     g7_dataset_statics()
+
+    # ---------------- f2: checkpoints in the reference's layout holding the reference's own objects ---------
+    f2_reference_checkpoints(R, NeTIMapper, PESigmas)
 
     # ---------------- G7 (text encoder): the real NeTICLIPTextModel incl. the bypass injection ------------------
     g_text_encoder_bypass(R, NeTIMapper, NeTIBatch, PESigmas)

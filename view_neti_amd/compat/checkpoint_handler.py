@@ -18,6 +18,36 @@ from . import config as cfgmod
 from .neti_modules import NeTIMapper
 
 
+class TextEncoderWeights:
+    """The slice of the reference's `text_encoder` module protocol that `load_learned_embed_in_clip` touches
+    (`get_input_embeddings().weight`, `resize_token_embeddings(n)`, checkpoint_handler.py:241,256,264), over the CLIP
+    weight dict the HIP engines consume (key `text_model.embeddings.token_embedding.weight`)."""
+    KEY = "text_model.embeddings.token_embedding.weight"
+
+    class _Emb:
+        def __init__(self, owner):
+            self._owner = owner
+
+        @property
+        def weight(self):
+            return self._owner.weights[TextEncoderWeights.KEY]
+
+    def __init__(self, clip_weights: Dict[str, torch.Tensor]):
+        self.weights = clip_weights
+
+    def get_input_embeddings(self):
+        return TextEncoderWeights._Emb(self)
+
+    def resize_token_embeddings(self, n: int):
+        E = self.weights[self.KEY]
+        if n > E.shape[0]:  # new rows: every one of them is assigned by the caller right after
+            self.weights[self.KEY] = torch.cat([E, torch.zeros(n - E.shape[0], E.shape[1], dtype=E.dtype,
+                                                               device=E.device)], 0)
+        elif n < E.shape[0]:
+            self.weights[self.KEY] = E[:n].clone()
+        return self.get_input_embeddings()
+
+
 class CheckpointHandler:
     def __init__(self, cfg, placeholder_view_tokens: List[str], placeholder_view_token_ids: List[int],
                  placeholder_object_tokens: List[str], placeholder_object_token_ids: List[int], save_root: Path,
@@ -106,3 +136,22 @@ class CheckpointHandler:
             lookup = dict(zip(placeholder_object_tokens, placeholder_object_token_ids))
             out[lookup[entry["placeholder_object_token"]]] = m
         return cfg, out
+
+    @staticmethod
+    def load_learned_embed_in_clip(learned_embeds_path: Path, text_encoder, tokenizer) -> Tuple[List[str], List[int]]:
+        """checkpoint_handler.py:232-267: add the saved placeholder tokens to the tokenizer, grow the token-embedding
+        table and write the saved rows into it.  `text_encoder` is anything with the two methods the reference calls
+        (`TextEncoderWeights` wraps the engines' weight dict).  -> (tokens, token ids)"""
+        loaded = torch.load(learned_embeds_path, map_location="cpu")
+        trained_tokens = list(loaded.keys())
+        dtype = text_encoder.get_input_embeddings().weight.dtype
+        embeds = [e.to(dtype) for e in loaded.values()]
+        if tokenizer.add_tokens(trained_tokens) == 0:
+            raise ValueError(f"The tokenizer already contains the token {trained_tokens[0]}. "
+                             f"Please pass a different `token` that is not already in the tokenizer.")
+        text_encoder.resize_token_embeddings(len(tokenizer))
+        ids = [tokenizer.convert_tokens_to_ids(t) for t in trained_tokens]
+        table = text_encoder.get_input_embeddings().weight
+        for token_id, embed in zip(ids, embeds):
+            table.data[token_id] = embed.to(table.device)
+        return trained_tokens, ids
