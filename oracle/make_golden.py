@@ -697,6 +697,53 @@ def main():
          seq=np.array(seq), sq=attn_self.to_q.weight, sk=attn_self.to_k.weight, sv=attn_self.to_v.weight,
          so=attn_self.to_out[0].weight, sbo=attn_self.to_out[0].bias, y_self=y_self)
 
+    # ---------------- G5b: the same processor at head dims the HIP kernels implement (40, 64), with gradients ---
+    for tag, C2, heads2, Dctx2 in (("d40", 320, 8, 128), ("d64", 128, 2, 64)):
+        gen = torch.Generator().manual_seed(88)
+        r16 = lambda x: x.half().float()  # f16-representable values: the GPU test feeds the very same numbers
+        proc = XTIAttenProc()
+        a_self, a_cross = Attn(C2, C2, heads2, gen), Attn(C2, Dctx2, heads2, gen)
+        for a in (a_self, a_cross):
+            for prm in list(a.to_q.parameters()) + list(a.to_k.parameters()) + list(a.to_v.parameters()) + \
+                    list(a.to_out.parameters()):
+                prm.data = r16(prm.data * (0.5 / 0.2) / (prm.shape[-1] ** 0.5))
+        Bn, Nq, Nk = 2, 24, 7
+        hs = r16(torch.randn(Bn, Nq, C2, generator=gen)).requires_grad_(True)
+        cd = {"this_idx": 15}
+        for i in (15, 0):
+            cd[f"CONTEXT_TENSOR_{i}"] = r16(torch.randn(Bn, Nk, Dctx2, generator=gen)).requires_grad_(True)
+            cd[f"CONTEXT_TENSOR_BYPASS_{i}"] = r16(torch.randn(Bn, Nk, Dctx2, generator=gen)).requires_grad_(True)
+        gy = r16(torch.randn(Bn, Nq, C2, generator=gen))
+        y_self = proc(a_self, hs, None)
+        (g_self,) = torch.autograd.grad((y_self * gy).sum(), hs)
+        y_t = proc(a_cross, hs, cd["CONTEXT_TENSOR_0"])
+        g_t = torch.autograd.grad((y_t * gy).sum(), [hs, cd["CONTEXT_TENSOR_0"]])
+        ys, gs, seq = [], [], []
+        for _ in range(2):
+            i = cd["this_idx"]
+            y = proc(a_cross, hs, cd)
+            seq.append(cd["this_idx"])
+            ys.append(y)
+            gs.append(torch.autograd.grad((y * gy).sum(), [hs, cd[f"CONTEXT_TENSOR_{i}"],
+                                                           cd[f"CONTEXT_TENSOR_BYPASS_{i}"]]))
+        assert seq == [0, 1]
+        with torch.no_grad():
+            mine = R.xti_attention(a_cross.to_q.weight, a_cross.to_k.weight, a_cross.to_v.weight, a_cross.to_out[0].weight,
+                                   a_cross.to_out[0].bias, heads2, hs, {"this_idx": 15, **{k: v for k, v in cd.items()
+                                                                                        if k != "this_idx"}})
+        close(mine, ys[0], 1e-5, f"G5b {tag} dict ctx")
+        h16 = lambda x: x.detach().half()
+        save(f"g5b_xti_attention_{tag}", heads=np.array(heads2), hs=h16(hs), gy=h16(gy),
+             wq=h16(a_cross.to_q.weight), wk=h16(a_cross.to_k.weight), wv=h16(a_cross.to_v.weight),
+             wo=h16(a_cross.to_out[0].weight), bo=a_cross.to_out[0].bias.detach(),
+             sq=h16(a_self.to_q.weight), sk=h16(a_self.to_k.weight), sv=h16(a_self.to_v.weight),
+             so=h16(a_self.to_out[0].weight), sbo=a_self.to_out[0].bias.detach(),
+             ctx15=h16(cd["CONTEXT_TENSOR_15"]), ctxb15=h16(cd["CONTEXT_TENSOR_BYPASS_15"]),
+             ctx0=h16(cd["CONTEXT_TENSOR_0"]), ctxb0=h16(cd["CONTEXT_TENSOR_BYPASS_0"]),
+             y_self=y_self.detach(), g_self=g_self, y_tensor=y_t.detach(), g_tensor_hs=g_t[0], g_tensor_ctx=g_t[1],
+             y0=ys[0].detach(), y1=ys[1].detach(), g0_hs=gs[0][0], g0_ctx=gs[0][1], g0_ctxb=gs[0][2],
+             g1_hs=gs[1][0], g1_ctx=gs[1][1], g1_ctxb=gs[1][2], seq=np.array(seq))
+
     # ---------------- G6: third-party CLIP text stack (transformers, random tiny weights) -----
     from transformers import CLIPTextModel
     from view_neti_amd import sd_config as sc

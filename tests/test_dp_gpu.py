@@ -1,0 +1,114 @@
+"""N > 1 on the HIP path (training/coach.py:728-733): two ranks share cuda:0 over the gloo backend and
+run the CAPTURED TrainStepEngine(world_size=2) — graph A (forward + backward), the all-reduce(sum) of the flat
+gradient bucket, graph B (AdamW with grad_div = world).  The ranks must end bit-identical, and must equal ONE
+process that feeds the same two micro-batches through gradient accumulation (mean of two micro-gradients: the same
+arithmetic).  Repeated for learnable_mode 3: three object mappers + the view mapper, the scene changing between
+steps, where only the active scene's segment and the view mapper cross the wire (BASELINE config 4's DP leg)."""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+STEPS, B, H, W, LR = 3, 2, 64, 64, 3e-3
+SCENES = [0, 2, 0]
+
+
+def _build(world, accum, mode3):
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.step import TrainStepEngine
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    cfg = sc.tiny()
+    D = cfg.clip.hidden_size
+    gen = torch.Generator().manual_seed(7)
+    mk = lambda: {k: v + 0.05 * torch.randn(v.shape, generator=gen) for k, v in init_mapper_state(64, 64, D).items()}
+    objs = [mk() for _ in range(3 if mode3 else 1)]
+    kw = {}
+    if mode3:
+        kw = dict(mapper_view=mk(), w_enc_view=fourier_frequencies([0.03, 2.0] + [0.5] * 12, 64, 0), norm_scale_view=0.35,
+                  alpha_view=0.3)
+    eng = TrainStepEngine(cfg, synth.unet_weights(cfg.unet), synth.vae_weights(cfg.vae), synth.clip_weights(cfg.clip), B,
+                          H, W, objs if mode3 else objs[0], fourier_frequencies([0.03, 2.0], 64, 0), 0.4, 0.2, lr=LR,
+                          world_size=world, grad_accum=accum, device_rng=False, **kw)
+    return cfg, eng
+
+
+def _feed(cfg, eng, step, shard, mode3):
+    """micro-batch `shard` (= the rank in the DP run) of optimizer step `step`: host-supplied data and noise"""
+    from view_neti_amd import synth
+    s = 100 * step + 10 * shard
+    ph, phv = cfg.clip.vocab_size - 3, cfg.clip.vocab_size - 4
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size, view_placeholder_id=phv if mode3 else None)
+    px = synth.gaussian((B, 3, H, W), s + 1).clamp(-1, 1)
+    if mode3:
+        eng.set_batch(px, ids, torch.full((B,), ph), torch.full((B,), phv), synth.gaussian((B, 12), s + 2).clamp(-1, 1),
+                      object_index=SCENES[step])
+    else:
+        eng.set_batch(px, ids, torch.full((B,), ph))
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(s + 3))
+    eng.set_noise(synth.gaussian((B, 4, H // 8, W // 8), s + 4), synth.gaussian((B, 4, H // 8, W // 8), s + 5), t)
+
+
+def _worker(rank, world, port, mode3, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", VNETI_NO_GN_FUSE="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, eng = _build(world, 1, mode3)
+    _feed(cfg, eng, 0, rank, mode3)
+    eng.capture()
+    assert eng.graph_b is not None, "world_size > 1 must split the step around the all-reduce"
+    p0 = eng.params.clone()
+    losses = []
+    for step in range(STEPS):
+        _feed(cfg, eng, step, rank, mode3)
+        assert eng.step() is True
+        losses.append(eng.loss())
+    torch.cuda.synchronize()
+    mine = eng.params.cpu()
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    if rank == 0:
+        torch.save({"all": gathered, "p0": p0.cpu(), "losses": losses, "opt_step": int(eng.opt_step.item()),
+                    "seg_step": eng.seg_step.cpu().tolist(), "grad_div": float(eng.hyper[5])}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode3", [False, True], ids=["mode0", "mode3"])
+def test_two_ranks_on_the_hip_engine_equal_grad_accumulation(tmp_path, mode3, monkeypatch):
+    out = str(tmp_path / "dp.pt")
+    port = 29600 + (os.getpid() % 300) + (50 if mode3 else 0)
+    mp.spawn(_worker, args=(2, port, mode3, out), nprocs=2, join=True)
+    res = torch.load(out)
+    a, b = res["all"]
+    assert torch.equal(a, b), "the two ranks' parameters must be bit-identical after the all-reduced steps"
+    assert res["opt_step"] == STEPS and res["grad_div"] == 2.0 and all(l == l and l > 0 for l in res["losses"])
+    # ---- one process, the same two micro-batches per step through gradient accumulation ----
+    monkeypatch.setenv("VNETI_NO_GN_FUSE", "1")  # same (atomics-free, deterministic) schedule as the workers
+    cfg, eng = _build(1, 2, mode3)
+    _feed(cfg, eng, 0, 0, mode3)
+    eng.capture()
+    assert torch.equal(eng.params.cpu(), res["p0"])
+    for step in range(STEPS):
+        _feed(cfg, eng, step, 0, mode3)
+        assert eng.step() is False
+        _feed(cfg, eng, step, 1, mode3)
+        assert eng.step() is True
+    torch.cuda.synchronize()
+    ref = eng.params.cpu()
+    upd = (ref - res["p0"]).abs().max().item()
+    dev = (a - ref).abs().max().item()
+    moved = (a != res["p0"]).float().mean().item()
+    print(f"[dp gpu {'mode3' if mode3 else 'mode0'}] max |update| {upd:.3e}; DP vs accumulation max dev {dev:.3e} "
+          f"({dev / upd:.2e} of the update); fraction of params moved {moved:.2f}; seg_step {res['seg_step']}")
+    assert upd > 0.5 * LR, "three AdamW steps move the weights by ~lr each"
+    assert dev <= 1e-5 * max(upd, 1e-12) + 1e-9, "DP (sum over ranks / world) must equal accumulation (sum over micro-steps / accum)"
+    if mode3:
+        n = eng.n_obj
+        assert torch.equal(a[n:2 * n], res["p0"][n:2 * n]), "the scene that never trained must not move"
+        assert res["seg_step"] == [2, 0, 1] and eng.seg_step.cpu().tolist() == [2, 0, 1]
