@@ -154,7 +154,8 @@ def cpu_baseline_bounded(args, timeout_s: int = 240):
     always finishes within minutes; a timeout is reported, never hidden."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", args.model, "--batch",
-           str(args.batch), "--resolution", str(args.resolution), "--cpu-resolution", str(args.cpu_resolution)]
+           str(args.batch), "--resolution", str(args.resolution), "--cpu-resolution", str(args.cpu_resolution),
+           "--cpu-steps", str(args.cpu_steps)]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
         for line in reversed(r.stdout.strip().splitlines()):
@@ -189,13 +190,24 @@ def cpu_baseline(args):
     ids = synth.input_ids(B, ph, cfg.clip.vocab_size)
     px, t = synth.pixel_values(B, res, res), synth.timesteps(B)
     eps, noise = synth.gaussian((B, 4, res // 8, res // 8), 3), synth.gaussian((B, 4, res // 8, res // 8), 4)
-    t0 = time.time()
-    loss, _ = R.train_step_loss(cfg, uw, vw, cw, sd, w_enc, 0.4, px, ids, torch.full((B,), ph), t, eps, noise)
-    loss.backward()
-    dt = time.time() - t0
+    def one_step():
+        for v in sd.values():
+            v.grad = None
+        t0 = time.time()
+        loss, _ = R.train_step_loss(cfg, uw, vw, cw, sd, w_enc, 0.4, px, ids, torch.full((B,), ph), t, eps, noise)
+        loss.backward()
+        return time.time() - t0, loss.item()
+
+    # 1 warm-up + 3 timed steps (the warm-up pays oneDNN primitive creation and the allocator's first touch)
+    warm, _ = one_step()
+    times, loss_v = [], 0.0
+    for _ in range(args.cpu_steps):
+        dt, loss_v = one_step()
+        times.append(dt)
+    dt = sum(times) / len(times)
     # FLOP ratio between the sample and one bench step (VAE and UNet scale with pixels, CLIP with batch)
     pix = (res / 512.0) ** 2
-    sample_gf = (1116.7 + 803.3 + 929.4) * pix + 212.8 + 216.0
+    sample_gf = ((1116.7 + 803.3 + 929.4) * pix + 212.8 + 216.0) * B
     bench_gf = ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512.0) ** 2
     est_steps_per_s = (sample_gf / dt) / bench_gf
     model = ""
@@ -206,10 +218,14 @@ def cpu_baseline(args):
                 break
     except OSError:
         pass
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else -1
     return {"value": est_steps_per_s, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/sd_ref.py fp32 torch-CPU restatement (diffusers not installable), 1 step fwd+bwd at bs=1 "
-                      f"{res}x{res} took {dt:.1f}s ({sample_gf / dt:.1f} GFLOP/s, loss {loss.item():.4f}); scaled to "
-                      f"bs={args.batch} {args.resolution}x{args.resolution} by algorithmic FLOPs; cpu='{model}'"}
+            "sample": f"oracle/sd_ref.py fp32 torch-CPU restatement (diffusers not installable): 1 warm-up ({warm:.1f}s) + "
+                      f"{len(times)} timed train steps (fwd+bwd) at bs={B} {res}x{res}, mean {dt:.2f}s min {min(times):.2f}s "
+                      f"({sample_gf / dt:.1f} GFLOP/s, loss {loss_v:.4f}); bs={B} instead of the bench's bs={args.batch} to "
+                      f"stay inside the wall-clock bound, scaled to bs={args.batch} {args.resolution}x{args.resolution} by "
+                      f"algorithmic FLOPs (x{bench_gf / sample_gf:.2f}); torch.get_num_threads()={torch.get_num_threads()}, "
+                      f"sched affinity {aff} cpus, os.cpu_count()={os.cpu_count()}, cpu='{model}'"}
 
 
 def main():
@@ -221,6 +237,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--resolution", type=int, default=512)
     ap.add_argument("--cpu-resolution", type=int, default=512)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps of the cpu_baseline leg (after 1 warm-up)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")

@@ -22,6 +22,9 @@ def _build(world, accum, mode3):
     from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
     cfg = sc.tiny()
     D = cfg.clip.hidden_size
+    # identical mapper initialisation on every rank: the reference gets it from the torch.manual_seed(0) inside every
+    # FourierPositionalEncodingNDims constructor (App. C Q1); init_mapper_state draws from the global generator
+    torch.manual_seed(0)
     gen = torch.Generator().manual_seed(7)
     mk = lambda: {k: v + 0.05 * torch.randn(v.shape, generator=gen) for k, v in init_mapper_state(64, 64, D).items()}
     objs = [mk() for _ in range(3 if mode3 else 1)]

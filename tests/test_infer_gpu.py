@@ -114,3 +114,43 @@ def test_pipeline_matches_oracle(cfg_name, kind, steps):
     print(f"[pipeline {cfg_name} {kind} x{steps}] final latents rel {ex:.3e}; image mean abs err {ei:.3e} "
           f"(image std {ref_img.std():.3f})")
     assert ex < 2e-2 and ei < 1e-2
+
+
+@pytest.mark.timeout(1200)
+def test_config5_full_size_sampler_step_and_decode():
+    """BASELINE config 5 at its real size (SD-2.1 shapes, 768x768, DDIM, CFG, object + pretrained-style view mapper):
+    two captured sampler steps + the VAE decoder run, shapes are right and everything stays finite; the captured step
+    equals the eager one."""
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.infer import InferenceEngine
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    cfg = sc.sd21()
+    B, H, W = 1, 768, 768
+    D = cfg.clip.hidden_size
+    dev = "cuda"
+    uw, dw, cw = (synth.unet_weights(cfg.unet, device=dev), synth.vae_decoder_weights(cfg.vae, device=dev),
+                  synth.clip_weights(cfg.clip, device=dev))
+    torch.manual_seed(0)
+    sdo, sdv = init_mapper_state(64, 64, D), init_mapper_state(64, 64, D)
+    norm = float(cw["text_model.embeddings.token_embedding.weight"][:1000].float().norm(dim=1).mean())
+    eng = InferenceEngine(cfg, uw, dw, cw, B, H, W, sdo, fourier_frequencies([0.03, 2.0], 64, 0), norm, 5.0,
+                          mapper_view=sdv, w_enc_view=fourier_frequencies([0.03, 2.0] + [0.5] * 12, 64, 0),
+                          norm_scale_view=norm, alpha_view=5.0)
+    del uw, dw, cw
+    ph, phv = cfg.clip.vocab_size - 3, cfg.clip.vocab_size - 4
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size, view_placeholder_id=phv)
+    neg = synth.input_ids(1, ph, cfg.clip.vocab_size)
+    neg[neg == ph] = 7
+    eng.set_negative_prompt(neg)
+    eng.set_prompt(ids, torch.full((B,), ph), torch.full((B,), phv), synth.gaussian((B, 12), 9).clamp(-1, 1))
+    lat = synth.gaussian((B, 4, H // 8, W // 8), 17)
+    img = eng.generate(lat, 2, 7.5, "ddim").clone()
+    x_graph = eng.x.clone()
+    assert img.shape == (B, H, W, 3) and bool(torch.isfinite(img).all()) and bool(torch.isfinite(x_graph).all())
+    assert 0.0 <= float(img.min()) and float(img.max()) <= 1.0 and float(img.std()) > 0
+    assert eng.unet.pred.shape[0] == 2 * B * (H // 8) * (W // 8)  # CFG-batched: unconditional + conditional halves
+    eng.generate(lat, 2, 7.5, "ddim", use_graph=False)
+    e = _rel(eng.x, x_graph)
+    print(f"[config 5 full size] sd21 768^2 DDIM x2: image mean {float(img.mean()):.4f} std {float(img.std()):.4f}; "
+          f"graph vs eager latents rel {e:.2e}; engine {eng.memory_bytes() / 2 ** 30:.1f} GiB")
+    assert e < 1e-2

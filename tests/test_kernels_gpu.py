@@ -27,10 +27,25 @@ def relerr(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item(), (a - b).abs().max().item()
 
 
-def check(name, got, ref, tol):
-    r, m = relerr(got, ref)
-    print(f"[{name}] rel={r:.3e} maxabs={m:.3e}")
+ELEM_K = 8.0
+
+
+def check(name, got, ref, tol, elem_k=ELEM_K):
+    """two bounds: the relative Frobenius norm (< tol), and an ELEMENT-WISE one so that a wrong tail row / column of a
+    large output cannot hide inside the norm: |got - ref| <= elem_k * tol * (rms(ref) + |ref|) for every element
+    (f16 rounding scales with the element, accumulation noise with the tensor's rms; a Gaussian error of sigma =
+    tol * rms stays under 6 sigma over 1e7 elements, a dropped or misplaced element is off by ~|ref| itself)."""
+    a, b = got.float().cpu(), ref.float().cpu()
+    r, m = relerr(a, b)
+    rms = b.pow(2).mean().sqrt()
+    excess = (a - b).abs() - elem_k * tol * (rms + b.abs())
+    worst = excess.max().item()
+    print(f"[{name}] rel={r:.3e} maxabs={m:.3e} elem-bound margin={-worst:.3e}")
     assert math.isfinite(r) and r < tol, f"{name}: rel err {r} (max abs {m}) >= {tol}"
+    if worst > 0:
+        idx = [int(i) for i in torch.unravel_index(excess.argmax(), excess.shape)]
+        raise AssertionError(f"{name}: element {idx} off by {(a - b)[tuple(idx)].item():.4e} (ref {b[tuple(idx)].item():.4e}, "
+                             f"rms {rms.item():.3e}): beyond the element-wise bound {elem_k}*{tol}*(rms+|ref|)")
 
 
 # ------------------------------------------------------------------------------------------ GEMM
