@@ -97,6 +97,15 @@ typedef struct vneti_gemm_desc {
      without re-reading the tensor). */
   float* gn_sums;
   int gn_hw, gn_cpg, gn_groups, gn_slots;
+  /* GEGLU (diffusers FeedForward: h, g = proj(x).chunk(2); h * gelu(g)) fused into the epilogue (f16 output, no
+     split-K, N % 8 == 0).  The projection's output columns are INTERLEAVED in groups of four, [h0..h3 g0..g3 h4..h7
+     g4..g7 ...] (the caller permutes the weight rows once at pack time), so one 16-byte chunk holds matching halves:
+       geglu = 1 (forward, the ff.net.0.proj GEMM): C receives the pre-activation in that layout (kept for the
+                 backward) and C2[m][n/2 + e] = C[m][n+e] * gelu(C[m][n+4+e]), e < 4 — the [M][N/2] input of ff.net.2;
+       geglu = 2 (backward, the ff.net.2 dgrad GEMM whose result d(h*gelu(g)) is [M][N]): gate_src is the saved
+                 pre-activation [M][2N]; C is [M][2N] in the same interleaved layout and receives
+                 d_h = d * gelu(g), d_g = d * h * gelu'(g); the [M][N] GEMM result itself is not stored. */
+  int geglu;
 } vneti_gemm_desc;
 
 int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream);

@@ -162,6 +162,46 @@ def test_gemm_gate_and_second_output(act, split, N):
     check(f"gemm out2 act{act} split{split}", out2, fn(out.float().cpu()), 1e-3)
 
 
+@pytest.mark.parametrize("hint", [0, 1, 3, 5, 7, 10, 12])
+@pytest.mark.parametrize("M,C", [(300, 64), (1024, 320)])
+def test_gemm_geglu_epilogues(hint, M, C):
+    """diffusers FeedForward GEGLU (h, g = proj(x).chunk(2); h * gelu(g)) fused into the GEMM epilogues
+    (vneti_gemm_desc.geglu): forward = the interleaved pre-activation + the gated output from ONE launch; backward =
+    the ff.net.2 dgrad GEMM writing d_h | d_g without storing d(h*gelu(g)).  Reference: torch autograd on the same
+    f16-rounded tensors, un-interleaved."""
+    from view_neti_amd import packing
+    ops = _ops()
+    F4 = 4 * C
+    x = rnd(M, C, seed=61)
+    W = rnd(2 * F4, C, scale=1.0 / math.sqrt(C), seed=62)
+    b = rnd(2 * F4, seed=63, dtype=torch.float32)
+    idx = packing.geglu_interleave_index(2 * F4)
+    p = torch.zeros(M, 2 * F4, dtype=torch.float16, device=DEV)
+    gg = torch.zeros(M, F4, dtype=torch.float16, device=DEV)
+    ops.gemm(x.to(DEV), packing.geglu_interleave(W).to(DEV), p, bias=packing.geglu_interleave(b).to(DEV), out2=gg, geglu=1,
+             split_k=1, tile_hint=hint)
+    torch.cuda.synchronize()
+    pre = (x.float() @ W.float().t() + b).half().float()            # [h | g], reference order
+    check(f"geglu fwd pre-activation (interleaved) hint{hint}", p, pre[:, idx], 2e-3)
+    pg = p.float().cpu()
+    inv = torch.empty_like(idx)
+    inv[idx] = torch.arange(2 * F4)
+    pu = pg[:, inv]                                                  # the GPU's own pre-activation, un-interleaved
+    check(f"geglu fwd gate hint{hint}", gg, pu[:, :F4] * F.gelu(pu[:, F4:]), 1e-3)
+    # backward: d = dy @ W2 (ff.net.2 dgrad), then through h * gelu(g)
+    dy = rnd(M, C, seed=64)
+    W2 = rnd(C, F4, scale=1.0 / math.sqrt(F4), seed=65)             # ff.net.2.weight [C][4C]
+    dp = torch.zeros(M, 2 * F4, dtype=torch.float16, device=DEV)
+    ops.gemm(dy.to(DEV), W2.t().contiguous().to(DEV), dp, gate=p, gate_act=ops.ACT_GELU, geglu=2, split_k=1, tile_hint=hint)
+    torch.cuda.synchronize()
+    d = (dy.float() @ W2.float()).half().float()
+    hg = pu.clone().requires_grad_(True)
+    (hg[:, :F4] * F.gelu(hg[:, F4:]) * d).sum().backward()
+    check(f"geglu bwd hint{hint}", dp, hg.grad[:, idx], 2e-3)
+    with pytest.raises(RuntimeError, match="split_k"):
+        ops.gemm(x.to(DEV), packing.geglu_interleave(W).to(DEV), p, out2=gg, geglu=1, split_k=2, tile_hint=3)
+
+
 @pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9])
 @pytest.mark.parametrize("Bn,HW,C", [(4, 64, 320), (2, 256, 128), (3, 576, 640), (2, 4096, 32 * 4)])
 def test_gemm_groupnorm_sums_and_fused_apply(hint, Bn, HW, C):

@@ -54,7 +54,32 @@ __device__ __forceinline__ u32x2 as_u32x2(half4 v) { return __builtin_bit_cast(u
 __device__ __forceinline__ float vn_silu(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float vn_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float vn_quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float vn_gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// Exact (erf) GELU without libm's erff (~40 instructions): Phi(x) = 0.5 * erfc(-x / sqrt 2) with erfc from Abramowitz &
+// Stegun 7.1.26 (|error| < 1.5e-7, far below the f16 the result is rounded to), evaluated on the erfc side so the
+// negative tail has no 1 - erf cancellation.  exp(-x^2 / 2) is shared with the derivative: gelu'(x) = Phi(x) + x phi(x).
+// Raw v_exp_f32 / v_rcp_f32: ~14 VALU operations, two of them transcendental.
+__device__ __forceinline__ void vn_gelu_parts(float x, float& cdf, float& xpdf) {
+  const float az = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float E = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);  // exp(-x^2 / 2)
+  const float erfc_az = poly * t * E;
+  cdf = 0.5f * (x >= 0.f ? 2.f - erfc_az : erfc_az);
+  xpdf = x * 0.3989422804014327f * E;
+}
+__device__ __forceinline__ float vn_gelu_erf(float x) {
+  float cdf, xpdf;
+  vn_gelu_parts(x, cdf, xpdf);
+  return x * cdf;
+}
+__device__ __forceinline__ float vn_gelu_erf_grad(float x) {
+  float cdf, xpdf;
+  vn_gelu_parts(x, cdf, xpdf);
+  return cdf + xpdf;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const half_t* dy, long l
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float gv = (float)g[j], dv = (float)d[j], hv = (float)h[j];
-    float cdf = 0.5f * (1.f + erff(gv * 0.70710678118654752f));
-    float pdf = 0.3989422804014327f * __expf(-0.5f * gv * gv);
+    float cdf, xpdf;
+    vn_gelu_parts(gv, cdf, xpdf);
     dh[j] = (half_t)(dv * gv * cdf);
-    dg[j] = (half_t)(dv * hv * (cdf + gv * pdf));
+    dg[j] = (half_t)(dv * hv * (cdf + xpdf));
   }
   *reinterpret_cast<half8*>(dp + (long long)r * lddp + c) = dh;
   *reinterpret_cast<half8*>(dp + (long long)r * lddp + C4 + c) = dg;
@@ -104,8 +104,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const half_t* dy, const ha
       float s = vn_sigmoid(1.702f * f);
       g = s * (1.f + 1.702f * f * (1.f - s));
     } else if (act == 3) {
-      float cdf = 0.5f * (1.f + erff(f * 0.70710678118654752f));
-      g = cdf + f * 0.3989422804014327f * __expf(-0.5f * f * f);
+      g = vn_gelu_erf_grad(f);
     } else {
       float s = vn_sigmoid(f);
       g = s * (1.f + f * (1.f - s));

@@ -44,6 +44,7 @@ struct GemmArgs {
   int gate_act, act2;
   float* gn_sums;  // [image][slot][G][2] running (sum, sum of squares) of the f16 output, see vneti_gemm_desc
   int gn_hw, gn_cpg, gn_G, gn_slots;
+  int geglu;  // 1: C2 = h * gelu(g) of the interleaved tile; 2: C[M][2N] = GEGLU backward against gate_src (see vneti.h)
   long long lda, ldb, ldc, ld_rowadd, ldr;
   long long strideA, strideB, strideC;
   uint32_t a_bytes, b_bytes;
@@ -74,8 +75,7 @@ __device__ __forceinline__ float act_grad(float f, int act) {
     float s = vn_sigmoid(1.702f * f);
     return s * (1.f + 1.702f * f * (1.f - s));
   } else if (act == 3) {
-    float cdf = 0.5f * (1.f + erff(f * 0.70710678118654752f));
-    return cdf + f * 0.3989422804014327f * __expf(-0.5f * f * f);
+    return vn_gelu_erf_grad(f);
   }
   float s = vn_sigmoid(f);
   return s * (1.f + f * (1.f - s));
@@ -509,12 +509,38 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
         }
+        if (g.geglu == 2) {
+          // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]
+          const half_t* pp = g.gate_src + (long long)m * g.ld_gate + 2 * n;
+          half_t* dp = Cb + (long long)m * g.ldc + 2 * n;
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const half8 pre = *reinterpret_cast<const half8*>(pp + 8 * c2);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = (float)v[4 * c2 + e], hh = (float)pre[e], gg = (float)pre[4 + e];
+              float cdf, xpdf;
+              vn_gelu_parts(gg, cdf, xpdf);
+              o[e] = (half_t)(d * gg * cdf);
+              o[4 + e] = (half_t)(d * hh * (cdf + xpdf));
+            }
+            *reinterpret_cast<half8*>(dp + 8 * c2) = o;
+          }
+          continue;
+        }
         if (g.gate_src) {
           half8 pre = *reinterpret_cast<const half8*>(g.gate_src + (long long)m * g.ld_gate + n);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)pre[e], g.gate_act));
         }
         *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
+        if (g.geglu == 1) {
+          half4 o2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o2[e] = (half_t)((float)v[e] * vn_gelu_erf((float)v[4 + e]));
+          *reinterpret_cast<half4*>(g.C2 + (long long)m * g.ldc2 + (n >> 1)) = o2;
+        }
         if (gn) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -528,7 +554,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
             }
           }
         }
-        if (g.C2) {
+        if (g.C2 && g.geglu == 0) {
           half8 o2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o2[e] = (half_t)apply_act((float)v[e], g.act2);
@@ -733,6 +759,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   g.gn_cpg = d->gn_cpg;
   g.gn_G = d->gn_groups;
   g.gn_slots = d->gn_slots;
+  g.geglu = d->geglu;
   g.lda = d->lda;
   g.ldb = d->ldb;
   g.ldc = d->ldc;
@@ -792,6 +819,19 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     VN_REQUIRE(!d->C2 || (d->act2 >= 0 && d->act2 <= 3 && d->ldc2 % 8 == 0), "gemm: bad C2 arguments");
   }
 
+  if (d->geglu) {
+    VN_REQUIRE(d->geglu == 1 || d->geglu == 2, "gemm: geglu must be 0, 1 or 2");
+    VN_REQUIRE(!f32 && batch == 1 && d->N % 8 == 0, "gemm: geglu needs f16 output, batch 1 and N %% 8 == 0");
+    VN_REQUIRE(d->split_k == 1, "gemm: geglu needs split_k = 1 (it lives in the fused epilogue)");
+    VN_REQUIRE(!d->gn_sums, "gemm: geglu and gn_sums are exclusive");
+    if (d->geglu == 1) {
+      VN_REQUIRE(d->C2 && d->ldc2 % 4 == 0 && !d->gate_src, "gemm: geglu forward needs C2 ([M][N/2]) and no gate");
+    } else {
+      VN_REQUIRE(d->gate_src && d->ld_gate % 8 == 0 && !d->C2 && !d->resid && !d->rowadd,
+                 "gemm: geglu backward needs gate_src ([M][2N] saved pre-activation) and a plain epilogue");
+      VN_REQUIRE(d->ldc % 8 == 0, "gemm: geglu backward writes [M][2N]: ldc %% 8");
+    }
+  }
   if (d->gn_sums) {
     VN_REQUIRE(!f32 && batch == 1, "gemm: gn_sums needs f16 output and batch 1");
     VN_REQUIRE(d->gn_hw >= 64 && d->gn_cpg >= 4 && d->gn_groups > 0 && d->gn_slots > 0 && d->N == d->gn_cpg * d->gn_groups &&

@@ -132,7 +132,7 @@ class Schedule:
         N = kw.get("N") or Bm.shape[-2]
         K = kw.get("K") or Bm.shape[-1]
         ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
-        return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32)
+        return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32, kw.get("geglu") or 0)
 
     def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12), reps=8):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
@@ -173,6 +173,8 @@ class Schedule:
                         sks = (0, 1) + (tuple(x for x in (2, 3, 4, 6, 8, 12)
                                               if x * 8 <= K_ // 64 and tiles * x <= 1024 and x * key[3] * M_ * N_ <= 16 * 2 ** 20)
                                         if tiles < 256 else ())
+                        if f.keywords.get("geglu"):
+                            sks = (1,)  # the GEGLU epilogues do not exist in the split-K reduce kernel
                         for sk in sks:
                             kw = dict(f.keywords)
                             kw["tile_hint"], kw["split_k"] = h, sk

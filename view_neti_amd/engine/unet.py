@@ -137,12 +137,15 @@ class UNetEngine(Schedule):
         self.fwd.append(partial(ops.gemm, o2, r["wo2"], h2, bias=bo2, resid=h1))
         # ---- feed-forward (GEGLU) ----
         n3, r["ln3"] = self._ln(h2, t + "norm3", w)
-        r["wff1"], bff1 = self._w16(w[t + "ff.net.0.proj.weight"]), self._w32(w[t + "ff.net.0.proj.bias"])
+        # GEGLU in the projection's epilogue: the rows of ff.net.0.proj are interleaved [h0..3 g0..3 h4..7 ...] at pack
+        # time so a 16-byte chunk of the output tile holds matching halves; `p` (kept for the backward) stays in that
+        # layout, `gg` = h * gelu(g) comes out of the same launch (no standalone geglu pass over the [M, 8C] tensor)
+        wff1_il = packing.geglu_interleave(w[t + "ff.net.0.proj.weight"])
+        r["wff1"], bff1 = self._w16(wff1_il), self._w32(packing.geglu_interleave(w[t + "ff.net.0.proj.bias"]))
         r["wff2"], bff2 = self._w16(w[t + "ff.net.2.weight"]), self._w32(w[t + "ff.net.2.bias"])
         p = self._buf((M, 8 * Cc))
         gg = self._buf((M, 4 * Cc))
-        self.fwd.append(partial(ops.gemm, n3, r["wff1"], p, bias=bff1))
-        self.fwd.append(partial(ops.geglu_fwd, p, gg))
+        self.fwd.append(partial(ops.gemm, n3, r["wff1"], p, bias=bff1, out2=gg, geglu=1, split_k=1))
         h3 = self._buf((M, Cc))
         self.fwd.append(partial(ops.gemm, gg, r["wff2"], h3, bias=bff2, resid=h2))
         r["w_out"], b_out = self._w16(w[name + "proj_out.weight"].reshape(Cc, Cc)), self._w32(w[name + "proj_out.bias"])
@@ -155,7 +158,7 @@ class UNetEngine(Schedule):
             tr = lambda a: self._w16(a.t())
             r["wk2d"], r["wv2d"] = tr(w[t + "attn2.to_k.weight"]), tr(w[t + "attn2.to_v.weight"])
             r["w_outd"] = tr(w[name + "proj_out.weight"].reshape(Cc, Cc))
-            r["wff2d"], r["wff1d"] = tr(w[t + "ff.net.2.weight"]), tr(w[t + "ff.net.0.proj.weight"])
+            r["wff2d"], r["wff1d"] = tr(w[t + "ff.net.2.weight"]), tr(wff1_il)
             r["wo2d"] = tr(w[t + "attn2.to_out.0.weight"])
             if need_dx:
                 r["wq2d"] = tr(w[t + "attn2.to_q.weight"])
@@ -175,10 +178,10 @@ class UNetEngine(Schedule):
         bw = self.bwd
         dh3 = self._tmp("tA", M, Cc)
         bw.append(partial(ops.gemm, dout, r["w_outd"], dh3))
-        dgg = self._tmp("tB", M, 4 * Cc)
-        bw.append(partial(ops.gemm, dh3, r["wff2d"], dgg))
+        # ff.net.2 dgrad with the GEGLU backward in its epilogue: the [M, 4C] result d(h*gelu(g)) is never stored, the
+        # launch writes dp = [d*gelu(g) | d*h*gelu'(g)] in p's interleaved layout
         dp = self._tmp("tC", M, 8 * Cc)
-        bw.append(partial(ops.geglu_bwd, dgg, r["p"], dp))
+        bw.append(partial(ops.gemm, dh3, r["wff2d"], dp, gate=r["p"], gate_act=ops.ACT_GELU, geglu=2, split_k=1))
         dn3 = self._tmp("tD", M, Cc)
         bw.append(partial(ops.gemm, dp, r["wff1d"], dn3))
         dh2 = self._tmp("tE", M, Cc)

@@ -51,6 +51,7 @@ class GemmDesc(C.Structure):
         ("gate_src", c_vp), ("ld_gate", c_ll), ("gate_act", c_int),
         ("C2", c_vp), ("ldc2", c_ll), ("act2", c_int),
         ("gn_sums", c_vp), ("gn_hw", c_int), ("gn_cpg", c_int), ("gn_groups", c_int), ("gn_slots", c_int),
+        ("geglu", c_int),
     ]
 
 

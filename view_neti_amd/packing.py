@@ -4,6 +4,9 @@ conv2d weight [Co][Ci][3][3]  -> forward  B[Co][tap*Ci + ci]          (K = 9*Ci 
                               -> dgrad    B[Ci][tap*Co + co]          (transposed gather, unflipped taps)
 linear weight [out][in]       -> forward  as is ([N][K]); dgrad = its transpose [in][out]
 1x1 conv weight [Co][Ci][1][1] is a linear weight.
+GEGLU projection [2*F][in] (rows 0..F-1 = h, F..2F-1 = gate) -> rows interleaved in groups of four,
+                              [h0..h3 g0..g3 h4..h7 g4..g7 ...], so that one 16-byte chunk of the GEMM's output tile
+                              holds matching halves and the epilogue can apply h * gelu(g) (vneti_gemm_desc.geglu).
 """
 from __future__ import annotations
 
@@ -31,3 +34,18 @@ def pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
     out = torch.zeros(*w.shape[:-1], kp, dtype=w.dtype, device=w.device)
     out[..., :k] = w
     return out
+
+
+def geglu_interleave_index(n2: int, device=None) -> torch.Tensor:
+    """row permutation of a GEGLU projection with 2*F = n2 outputs: position 8q+e takes h[4q+e] (e < 4) or
+    gate[4q+e-4] (e >= 4)"""
+    F = n2 // 2
+    assert n2 % 8 == 0
+    r = torch.arange(n2, device=device)
+    q, e = r // 8, r % 8
+    return torch.where(e < 4, 4 * q + e, F + 4 * q + e - 4)
+
+
+def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
+    """weight [2F][in] or bias [2F] -> the interleaved row order"""
+    return w[geglu_interleave_index(w.shape[0], w.device)].contiguous()
