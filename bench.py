@@ -88,9 +88,19 @@ def roofline_pass(eng, reps=3):
         N, K = kw.get("N") or Bm.shape[-2], kw.get("K") or Bm.shape[-1]
         batch = kw.get("batch") or 1
         tile = kw.get("tile_hint") or ops.gemm_select_tile(M, N, batch)
-        g = groups.setdefault(tile, dict(launches=[], flops=0.0))
+        g = groups.setdefault(tile, dict(launches=[], flops=0.0, bytes=0.0))
         g["launches"].append(f)
         g["flops"] += 2.0 * M * N * K * batch
+        # algorithmic HBM bytes of the launch: every operand once — A (the plain matrix, or the NHWC image an implicit
+        # conv gathers from: NOT its 9x im2col expansion), the weights, the output, plus the fused epilogue operands
+        conv = kw.get("conv")
+        a_bytes = (M // (conv["Ho"] * conv["Wo"])) * conv["Hi"] * conv["Wi"] * conv["Ci"] * 2 if conv else M * K * 2 * batch
+        out = f.args[2]
+        c_cols = N * (2 if kw.get("geglu") == 2 else 1)
+        extra = sum(M * c * 2 for c, key in ((N, "resid"), (N, "out2"), (c_cols, "gate")) if kw.get(key) is not None)
+        if kw.get("geglu") == 1:
+            extra -= M * N  # out2 of the GEGLU projection is [M, N/2]
+        g["bytes"] += a_bytes + N * K * 2 * batch + M * c_cols * out.element_size() * batch + extra
     out = {}
     for tile, g in groups.items():
         for f in g["launches"]:
@@ -106,6 +116,7 @@ def roofline_pass(eng, reps=3):
         total_ms = s.elapsed_time(e) / reps
         n = len(g["launches"])
         out[tile] = dict(n=n, total_ms=total_ms, avg_us=total_ms * 1e3 / n, flops_per_launch=g["flops"] / n,
+                         bytes_per_launch=g["bytes"] / n,
                          tflops=g["flops"] / (total_ms * 1e-3) / 1e12)
     return out
 
@@ -316,6 +327,9 @@ def main():
                          **pmc_traffic(TILE_NAMES[dom]),
                          "launches_per_step": d["n"], "avg_launch_us": d["avg_us"],
                          "algorithmic_gflop_per_launch": d["flops_per_launch"] / 1e9,
+                         "algorithmic_bytes_per_launch": d["bytes_per_launch"],
+                         "algorithmic_bytes_note": "mean over this tile's launches of A (image for implicit convs) + weights "
+                                                   "+ output + fused epilogue operands, each once; compare with `traffic`",
                          "all_gemm_tiles": {TILE_NAMES[k]: {"launches": v["n"], "ms_per_step": v["total_ms"],
                                                             "tflops": v["tflops"]} for k, v in rf.items()}},
         }

@@ -326,7 +326,11 @@ long long vneti_mapper_rowgrad_floats(int R, int hidden, int D, int has_bypass);
 int vneti_mapper_fwd(const float* params, const int* slot, long long slot_stride, const float* data,
                      int nfeat, const float* w_enc,
                      const float* hidden_mask, float norm_scale, float* word, float* bypass,
-                     float* save, int R, int enc_dim, int hidden, int D, int has_bypass, void* stream);
+                     float* save, int R, int enc_dim, int hidden, int D, int has_bypass, const float* enc_in,
+                     void* stream);
+/* enc_in (optional, f32 [R][enc_dim]): the first layer's input is given instead of being the Fourier encoding of
+ * `data` (then data / w_enc may be NULL) — the legacy mapper of arch_view_net <= 14, whose first-layer input is the
+ * output of its trainable input_layer (vneti_mapper_legacy_input_fwd below). */
 /* parameter gradients (the only wgrad of the whole train step).  d(word) for mapper row r is
  * read from dword_src + dword_rows[r]*ld_src (the placeholder rows of the embedding gradient). */
 int vneti_mapper_bwd(const float* params, const int* slot, long long slot_stride,
@@ -334,7 +338,23 @@ int vneti_mapper_bwd(const float* params, const int* slot, long long slot_stride
                      const float* word, const float* dword_src, const int* dword_rows,
                      long long ld_src, const float* dbypass, const float* save, float* rowgrads,
                      float* grads, int accumulate, int R, int enc_dim, int hidden, int D,
-                     int has_bypass, void* stream);
+                     int has_bypass, float* denc, void* stream);
+/* denc (optional, f32 [R][enc_dim]) receives d(loss)/d(first-layer input): what the legacy path back-propagates
+ * into its input_layer.
+ *
+ * Legacy object mapper (the reference's dataclass default arch_view_net = 0; models/positional_encoding.py:10-51,
+ * models/neti_mapper.py:155-163,200-206): e[(l,b)] = W_in v + b_in with v = cat[sin(w x), cos(w x)] / |.| of the RAW
+ * x = (timestep_b, l), w_pe f32 [pe_dim/2][2] (NeTIPositionalEncoding.w), W_in f32 [enc_dim][pe_dim] initialised from
+ * the 10 x 16 anchor encodings.  params_in / grads_in: [W_in | b_in], vneti_mapper_legacy_input_params() floats; `slot`
+ * as above.  The backward recomputes v and writes (or accumulates) dW_in = sum_r denc[r] (x) v_r, db_in = sum_r denc[r];
+ * nl*Bn <= 128 rows. */
+long long vneti_mapper_legacy_input_params(int enc_dim, int pe_dim);
+int vneti_mapper_legacy_input_fwd(const float* params_in, const int* slot, long long slot_stride,
+                                  const void* timesteps_i64, const float* w_pe, float* enc_out, int nl, int Bn,
+                                  int enc_dim, int pe_dim, void* stream);
+int vneti_mapper_legacy_input_bwd(const void* timesteps_i64, const float* w_pe, const float* denc, float* grads_in,
+                                  const int* slot, long long slot_stride, int accumulate, int nl, int Bn, int enc_dim,
+                                  int pe_dim, void* stream);
 /* NeTICLIPTextEmbeddings.forward (models/net_clip_text_embedding.py:34-137) for all layers:
  * X[(l,b,pos)][D] f32 = (pos == pos_obj[b] ? word_obj[(l,b)] : pos == pos_view[b] ? word_view : E[ids[b][pos]]) + P[pos] */
 int vneti_text_embed(const float* tok_emb, const float* pos_emb, const void* ids_i64,

@@ -484,6 +484,52 @@ def f2_reference_checkpoints(R, NeTIMapper, PESigmas):
         print(f"wrote {os.path.join(OUT, f)} ({os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB)")
 
 
+def g9_legacy_mapper(R, NeTIMapper, PESigmas):
+    """SURVEY a5' / G9: the reference's DATACLASS-DEFAULT object mapper (arch_view_net = 0, arch_view_disable_tl = True,
+    use_positional_encoding = 1, arch_mlp_hidden_dims = 128: training/config.py:89-130) — NeTIPositionalEncoding
+    (2048-d normalised sin/cos of raw (t, l)) -> anchor-initialised input_layer(2048 -> 160) -> MLP(h) -> 2D.  Captures
+    the encoder frequencies, the anchor initialisation (row norms 1), the outputs and the parameter gradients.  A small
+    output width keeps the fixture small; the parameter count at D = 768 is asserted from shapes: 563 616 without
+    `encoder.w` (SURVEY's 565 664 counts the 1024x2 frequencies, which a CUDA run keeps out of state_dict, App. C Q2)."""
+    from models.positional_encoding import NeTIPositionalEncoding
+    D, h = 24, 128
+    torch.manual_seed(77)
+    m = NeTIMapper(embedding_type="object", output_dim=D, arch_mlp_hidden_dims=h, use_nested_dropout=False,
+                   norm_scale=torch.tensor(0.4), pe_sigmas=PESigmas(sigma_t=0.03, sigma_l=2.0), output_bypass=True,
+                   bypass_unconstrained=False, output_bypass_alpha=0.2, placeholder_object_token="<obj>").eval()
+    assert isinstance(m.encoder, NeTIPositionalEncoding) and m.arch_view_net == 0
+    w_pe = m.encoder.w.detach().clone()
+    init = m.input_layer.weight.detach().clone()
+    close(R.neti_pe_init_layer(w_pe), init, 1e-6, "G9 input_layer anchor initialisation")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items() if k != "encoder.w"}
+    n768 = sum(v.numel() for k, v in sd.items() if "output_layer" not in k) + (128 * 2 * 768 + 2 * 768)
+    assert n768 == 563616 and n768 + w_pe.numel() == 565664, n768
+    gen = torch.Generator().manual_seed(78)
+    for k in sd:
+        if k != "input_layer.weight":  # stays the anchor initialisation: the test rebuilds it from w_pe (1.3 MB saved)
+            sd[k] = sd[k] + 0.05 * torch.randn(sd[k].shape, generator=gen)
+    m.load_state_dict({**sd, **({"encoder.w": m.state_dict()["encoder.w"]} if "encoder.w" in m.state_dict() else {})})
+    t = torch.tensor([10.0, 500.0, 999.0, 3.0])
+    lay = torch.tensor([0.0, 7.0, 15.0, 2.0])
+    out = m(timestep=t, unet_layer=lay, input_ids_placeholder_view=None, truncation_idx=None)
+    gw = torch.randn(out.word_embedding.shape, generator=gen)
+    gb = torch.randn(out.bypass_output.shape, generator=gen)
+    ((out.word_embedding * gw).sum() + (out.bypass_output * gb).sum()).backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if k != "encoder.w" and p.grad is not None}
+    po = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    wo, bo = R.mapper_forward_legacy(po, w_pe, t, lay, 0.4)
+    ((wo * gw).sum() + (bo * gb).sum()).backward()
+    close(R.neti_pe_encode(w_pe, t, lay), m.encoder.encode(t, lay), 1e-6, "G9 encode")
+    close(wo, out.word_embedding, 1e-5, "G9 legacy word")
+    close(bo, out.bypass_output, 1e-5, "G9 legacy bypass")
+    for k in grads:
+        close(po[k].grad, grads[k], 1e-4, f"G9 grad {k}")
+    save("g9_legacy_mapper", w_pe=w_pe, init_row_norms=init.norm(dim=1), init_rows_0_17_159=init[[0, 17, 159]], t=t, l=lay,
+         enc=m.encoder.encode(t, lay), word=out.word_embedding, bypass=out.bypass_output, gw=gw, gb=gb,
+         n_params_768=np.array(n768), **{"sd." + k: v for k, v in sd.items() if k != "input_layer.weight"},
+         **{"grad." + k: (v if v.numel() < 50000 else v[:, :16]) for k, v in grads.items()})
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference not mounted; fixtures can only be generated in the build container")
@@ -778,6 +824,9 @@ def main():
     # ---------------- G6 (config post-init dumps) and G7 (dataset statics) ---------------------------------
     g6_config_dumps()
     g7_dataset_statics()
+
+    # ---------------- G9: the legacy (dataclass-default) object mapper ------------------------------------------
+    g9_legacy_mapper(R, NeTIMapper, PESigmas)
 
     # ---------------- f2: checkpoints in the reference's layout holding the reference's own objects ---------
     f2_reference_checkpoints(R, NeTIMapper, PESigmas)

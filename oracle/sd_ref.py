@@ -86,6 +86,54 @@ def mapper_forward(p: W, w_enc: torch.Tensor, timestep: torch.Tensor, unet_layer
     return word, bypass
 
 
+def neti_pe_encode(w: torch.Tensor, t: torch.Tensor, l: torch.Tensor) -> torch.Tensor:
+    """models/positional_encoding.py:23-41 (legacy `NeTIPositionalEncoding.encode`, batched branch): x = (t, l) RAW
+    (timestep 0..999, layer index 0..15 — no [-1,1] scaling), v = cat[sin(w x), cos(w x)] over num_w = 1024
+    frequencies, L2-normalised per sample -> (bs, 2048).  (|v| = sqrt(num_w) exactly, sin^2 + cos^2 = 1.)"""
+    x = torch.stack([t.float(), l.float()], dim=1).t()
+    v = torch.cat([torch.sin(w @ x), torch.cos(w @ x)])
+    return (v / v.norm(dim=0)).t()
+
+
+def neti_pe_init_layer(w: torch.Tensor, num_time_anchors: int = 10, num_layers: int = 16) -> torch.Tensor:
+    """models/positional_encoding.py:43-51: the (anchors*layers, 2048) initial weight of the legacy `input_layer` —
+    row (i*num_layers + j) is the normalised encoding of the anchor (t = i * (1000 // anchors), l = j)."""
+    rows = []
+    for t_anchor in range(0, 1000, 1000 // num_time_anchors):
+        for l_anchor in range(num_layers):
+            x = torch.tensor([float(t_anchor), float(l_anchor)])
+            v = torch.cat([torch.sin(w @ x), torch.cos(w @ x)])
+            rows.append(v / v.norm())
+    return torch.stack(rows)
+
+
+def mapper_forward_legacy(p: W, w_pe: torch.Tensor, timestep: torch.Tensor, unet_layer: torch.Tensor,
+                          norm_scale: Optional[float], output_bypass: bool = True,
+                          truncation_mask: Optional[torch.Tensor] = None):
+    """models/neti_mapper.py:165-206,369-374 with arch_view_net <= 14 (the dataclass default 0, training/config.py:130),
+    embedding_type 'object', use_positional_encoding 1: encode (above) -> input_layer Linear(2048, anchors*layers)
+    (:155-163) -> net (Linear-LN-LeakyReLU x2, h = arch_mlp_hidden_dims, :148-152) -> [nested dropout mask] ->
+    output_layer -> get_output (:416-438).
+    p keys: input_layer.{weight,bias}, net.0/1/3/4.{weight,bias}, output_layer.0.{weight,bias}."""
+    enc = neti_pe_encode(w_pe, timestep, unet_layer)
+    e = F.linear(enc, p["input_layer.weight"], p["input_layer.bias"])
+    h = F.linear(e, p["net.0.weight"], p["net.0.bias"])
+    h = F.leaky_relu(F.layer_norm(h, (h.shape[-1],), p["net.1.weight"], p["net.1.bias"]))
+    h = F.linear(h, p["net.3.weight"], p["net.3.bias"])
+    h = F.leaky_relu(F.layer_norm(h, (h.shape[-1],), p["net.4.weight"], p["net.4.bias"]))
+    if truncation_mask is not None:
+        h = h * truncation_mask
+    out = F.linear(h, p["output_layer.0.weight"], p["output_layer.0.bias"])
+    if output_bypass:
+        dim = out.shape[1] // 2
+        word, bypass = out[:, :dim], out[:, dim:]
+    else:
+        word, bypass = out, None
+    if norm_scale is not None:
+        word = F.normalize(word, dim=-1) * norm_scale
+    return word, bypass
+
+
 # ------------------------------------------------------------------------------------------
 # third-party: CLIP text encoder stack (transformers 4.27.4 CLIPEncoder), SURVEY App. A.2
 # ------------------------------------------------------------------------------------------
@@ -394,8 +442,11 @@ def text_conditioning(clip_w: W, clip_cfg, mapper_p: W, w_enc, norm_scale, input
     B = input_ids.shape[0]
     for l in range(n_layers):
         layer = torch.full((B,), float(l))
-        word, byp = mapper_forward(mapper_p, w_enc, timesteps, layer, norm_scale, True, n_layers,
-                                   truncation_mask=None if hidden_masks is None else hidden_masks[l])
+        tm = None if hidden_masks is None else hidden_masks[l]
+        if "input_layer.weight" in mapper_p:  # legacy object mapper (arch_view_net <= 14): w_enc is NeTIPositionalEncoding.w
+            word, byp = mapper_forward_legacy(mapper_p, w_enc, timesteps, layer, norm_scale, True, truncation_mask=tm)
+        else:
+            word, byp = mapper_forward(mapper_p, w_enc, timesteps, layer, norm_scale, True, n_layers, truncation_mask=tm)
         kw = {}
         if view is not None:
             vm = view.get("hidden_masks")

@@ -253,3 +253,43 @@ def test_coach_device_input_pipeline_matches_host(tmp_path, aug_key, flip):
     dev.train()
     assert dev.engine.opt_step.item() == 3 and not torch.equal(p0, dev.engine.params)
     assert np.isfinite(dev.engine.loss())
+
+
+def test_coach_reference_default_mapper_config_trains(tmp_path):
+    """SURVEY a5': `Coach(RunConfig())`-style defaults for the mapper — arch_view_net 0 / arch_view_disable_tl True /
+    arch_mlp_hidden_dims 128 / nested dropout on (training/config.py:89-130) — i.e. the LEGACY object mapper with its
+    trainable input_layer: trains, checkpoints, and the checkpoint (pickled NeTIPositionalEncoding included) loads back
+    into the same parameters."""
+    from view_neti_amd.compat import config as C
+    from view_neti_amd.compat.checkpoint_handler import CheckpointHandler
+    from view_neti_amd.compat.coach import Coach
+    from view_neti_amd.engine.text import flatten_mapper_state
+    root = tmp_path / "toys"
+    root.mkdir()
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 255, (90, 120, 3), dtype=np.uint8)).save(root / f"{i}.png")
+    cfg = C.parse(C.RunConfig, [
+        "--data.train_data_dir", str(root), "--data.placeholder_object_token", "<toy>", "--data.resolution", "64",
+        "--data.dataloader_num_workers", "0", "--model.word_embedding_dim", "128", "--optim.max_train_steps", "3",
+        "--optim.train_batch_size", "2", "--optim.gradient_accumulation_steps", "1", "--optim.mixed_precision", "fp16",
+        "--log.save_steps", "100", "--eval.validation_steps", "100", "--log.exp_dir", str(tmp_path / "out"),
+        "--log.exp_name", "legacy"])
+    assert cfg.model.arch_view_net == 0 and cfg.model.arch_view_disable_tl and cfg.model.use_nested_dropout
+    cfg.log.exp_dir = cfg.log.exp_dir / cfg.log.exp_name
+    cfg.log.logging_dir = cfg.log.exp_dir / cfg.log.logging_dir
+    torch.manual_seed(cfg.seed)
+    coach = Coach(cfg)
+    eng = coach.engine
+    n_std = 160 * 128 + 128 * 3 + 128 * 128 + 128 * 3 + 256 * 128 + 256
+    assert eng.params.numel() == n_std + 160 * 2048 + 160 and eng.text.mo.legacy_w_pe.shape == (1024, 2)
+    p0 = eng.params.clone()
+    coach.train()
+    assert eng.opt_step.item() == 3 and torch.isfinite(eng.params).all()
+    moved_in = (eng.params[n_std:] != p0[n_std:]).float().mean().item()
+    assert moved_in > 0.9, "the input_layer is trained too"
+    tok_id = coach.placeholder_object_token_ids[0]
+    _, lookup = CheckpointHandler.load_mapper(cfg.log.exp_dir / "mapper-final_object.pt", "object", ["<toy>"], [tok_id])
+    m = lookup[tok_id]
+    assert m.legacy and torch.equal(m.encoder.w, coach.mapper_object_lookup[tok_id].encoder.w)
+    assert torch.equal(flatten_mapper_state(m.mapper_state()), eng.params.cpu())

@@ -304,3 +304,29 @@ def test_g7_dataset_statics():
         close(p, v["params"], 0)
         assert key == v["key"]
     assert TID.dtu_cam_params_to_token(torch.tensor(rec["novel_params"])) == rec["novel_token"]
+
+
+def test_g9_legacy_mapper():
+    """SURVEY a5' — the reference's dataclass-default object mapper (arch_view_net 0: NeTIPositionalEncoding ->
+    anchor-initialised input_layer -> MLP 128), models/positional_encoding.py:10-51, models/neti_mapper.py:155-163,
+    :369-374: encoder output, anchor rows, outputs and parameter gradients of the real module."""
+    f = load("g9_legacy_mapper")
+    w_pe = T(f["w_pe"])
+    assert w_pe.shape == (1024, 2) and int(f["n_params_768"]) == 563616
+    init = R.neti_pe_init_layer(w_pe)
+    assert init.shape == (160, 2048)
+    close(init.norm(dim=1), f["init_row_norms"], 1e-6)
+    close(init.norm(dim=1), torch.ones(160), 1e-6)
+    close(init[[0, 17, 159]], f["init_rows_0_17_159"], 1e-6)
+    t, lay = T(f["t"]), T(f["l"])
+    close(R.neti_pe_encode(w_pe, t, lay), f["enc"], 1e-6)
+    p = {k: v.clone().requires_grad_(True) for k, v in _sd(f).items()}
+    p["input_layer.weight"] = init.clone().requires_grad_(True)
+    word, byp = R.mapper_forward_legacy(p, w_pe, t, lay, 0.4)
+    close(word, f["word"])
+    close(byp, f["bypass"])
+    ((word * T(f["gw"])).sum() + (byp * T(f["gb"])).sum()).backward()
+    for k, v in f.items():
+        if k.startswith("grad."):
+            g = p[k[5:]].grad
+            close(g if g.numel() < 50000 else g[:, :16], v, 1e-4)

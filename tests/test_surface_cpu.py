@@ -334,3 +334,40 @@ def test_f2_diffusers_layout_safetensors(tmp_path):
     os.remove(tmp_path / "unet" / "model-00001.safetensors")
     with pytest.raises(KeyError, match="missing from checkpoint"):
         sd_weights.load_sd_weights(cfg, str(tmp_path), device="cpu")
+
+
+def test_legacy_mapper_module_matches_reference_and_round_trips(tmp_path):
+    """SURVEY a5': compat NeTIMapper(arch_view_net=0) — the reference's dataclass default — against G9 (outputs of the real
+    module), and through a checkpoint whose pickled NeTIPositionalEncoding carries the un-seeded frequencies."""
+    from view_neti_amd.compat.neti_modules import NeTIPositionalEncoding
+    f = np.load(os.path.join(_G, "g9_legacy_mapper.npz"))
+    D = f["word"].shape[1]
+    m = NeTIMapper("object", D, 128, 0.4, arch_view_net=0, placeholder_object_token="<obj>")
+    assert m.legacy and isinstance(m.encoder, NeTIPositionalEncoding) and m.enc_dim == 160 and m.pe_dim == 2048
+    assert type(m.encoder).__module__ == "models.positional_encoding"
+    assert torch.allclose(m.input_layer.weight.norm(dim=1), torch.ones(160), atol=1e-5)  # anchor rows are unit vectors
+    n768 = sum(v.numel() for v in NeTIMapper("object", 768, 128, 0.4, arch_view_net=0).mapper_state().values())
+    assert n768 == int(f["n_params_768"]) == 563616
+    m.encoder.w = torch.from_numpy(f["w_pe"])
+    sd = {k[3:]: torch.from_numpy(v) for k, v in f.items() if k.startswith("sd.")}
+    sd["input_layer.weight"] = m.encoder.init_layer(10, 16)
+    assert set(sd) == set(m.mapper_state())
+    m.load_state_dict(sd, strict=False)
+    t, lay = torch.from_numpy(f["t"]), torch.from_numpy(f["l"])
+    with torch.no_grad():
+        w, b = m(t, lay)
+    assert torch.allclose(w, torch.from_numpy(f["word"]), atol=1e-5) and torch.allclose(b, torch.from_numpy(f["bypass"]), atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        NeTIMapper("view", D, 64, 0.4, arch_view_net=0)
+    # checkpoint round trip: the frequencies survive only through the pickled encoder
+    cfg = C.RunConfig(data=C.DataConfig(train_data_dir="x", placeholder_object_token="<obj>"),
+                      model=C.ModelConfig(word_embedding_dim=D, target_norm_object=0.4, use_nested_dropout=False))
+    assert cfg.model.arch_view_net == 0 and cfg.model.arch_mlp_hidden_dims == 128  # the reference's defaults
+    h = CheckpointHandler(cfg, [], [], ["<obj>"], [96], tmp_path)
+    h.save_mapper({96: m}, None, "mapper-steps-1.pt")
+    _, lookup = CheckpointHandler.load_mapper(tmp_path / "mapper-steps-1_object.pt", "object", ["<obj>"], [96])
+    m2 = lookup[96]
+    assert m2.legacy and torch.equal(m2.encoder.w, m.encoder.w)
+    with torch.no_grad():
+        w2, b2 = m2(t, lay)
+    assert torch.equal(w2, w) and torch.equal(b2, b)

@@ -113,3 +113,70 @@ def test_text_engine_tiny(with_view, unc_obj, unc_view, dropout):
         cosv = torch.nn.functional.cosine_similarity(gv.float().cpu(), ref_gv, dim=0).item()
         print(f"[text view] view-mapper grad rel {egv:.3e} cos {cosv:.6f}")
         assert egv < 3e-2 and cosv > 0.999
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_text_engine_legacy_object_mapper(dropout):
+    """SURVEY a5': the reference's dataclass-default object mapper (arch_view_net 0 — NeTIPositionalEncoding of the raw
+    (t, l), anchor-initialised trainable input_layer 2048 -> 160, MLP h = 128; models/positional_encoding.py:10-51,
+    models/neti_mapper.py:155-163) on the HIP text path: both contexts and ALL parameter gradients (input_layer included)
+    against the oracle, whose legacy restatement G9 pins to the real module."""
+    from oracle import sd_ref as R
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.text import MapperState, TextEngine, flatten_mapper_state, unflatten_mapper_state
+    dev = "cuda"
+    cfg = sc.tiny().clip
+    D, L, nl, B, E, h, P2 = cfg.hidden_size, cfg.max_positions, 16, 2, 160, 128, 2048
+    w = synth.clip_weights(cfg)
+    wr = {k: (v.half().float() if (k.endswith("weight") and v.dim() == 2 and "embedding" not in k) else v)
+          for k, v in w.items()}
+    ph_obj = cfg.vocab_size - 3
+    ids = synth.input_ids(B, ph_obj, cfg.vocab_size, L)
+    ids[1] = torch.roll(ids[1], 3)
+    t = torch.tensor([17, 803])
+    gen = torch.Generator().manual_seed(5)
+    w_pe = torch.randn(1024, 2, generator=gen) * torch.tensor([0.03, 2.0])
+    rn = lambda *s, sc_=0.1: torch.randn(*s, generator=gen) * sc_
+    sd = {"input_layer.weight": R.neti_pe_init_layer(w_pe) + rn(E, P2, sc_=0.02), "input_layer.bias": rn(E),
+          "net.0.weight": rn(h, E, sc_=0.15), "net.0.bias": rn(h), "net.1.weight": 1 + rn(h), "net.1.bias": rn(h),
+          "net.3.weight": rn(h, h, sc_=0.1), "net.3.bias": rn(h), "net.4.weight": 1 + rn(h), "net.4.bias": rn(h),
+          "output_layer.0.weight": rn(2 * D, h, sc_=0.15), "output_layer.0.bias": rn(2 * D)}
+    flat = flatten_mapper_state(sd)
+    back = unflatten_mapper_state(flat, E, h, 2 * D, P2)
+    assert all(torch.equal(back[k], sd[k]) for k in sd) and flat.numel() == sum(v.numel() for v in sd.values())
+    ctx_k = torch.zeros(nl, B * L, D, dtype=torch.float16, device=dev)
+    ctx_v = torch.zeros_like(ctx_k)
+    dk = (synth.gaussian((nl, B * L, D), 11) * 0.5).half()
+    dv = (synth.gaussian((nl, B * L, D), 12) * 0.5).half()
+    po = flat.to(dev)
+    go = torch.full_like(po, 7.0)  # must be overwritten, not accumulated into
+    rng_state = torch.tensor([77, 5], dtype=torch.int32, device=dev)
+    mo = MapperState(po, None, 0.4, 0.2, hidden=h, enc_dim=E, nested_dropout_prob=0.5 if dropout else 0.0,
+                     legacy_w_pe=w_pe.to(dev))
+    eng = TextEngine(cfg, wr, nl, B, t.to(dev), ctx_k, ctx_v, dk.to(dev), dv.to(dev), mo, go, rng_state=rng_state)
+    eng.set_batch(ids, torch.full((B,), ph_obj))
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    masks = eng.hidden_mask_obj.cpu().view(nl, B, -1) if dropout else None
+    p_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hs = R.text_conditioning(wr, cfg, p_o, w_pe, 0.4, ids, torch.full((B,), ph_obj), t, alpha=0.2, n_layers=nl,
+                             hidden_masks=masks)
+    rk = torch.stack([hs[f"CONTEXT_TENSOR_{i}"] for i in range(nl)]).reshape(nl, B * L, D)
+    rv = torch.stack([hs[f"CONTEXT_TENSOR_BYPASS_{i}"] for i in range(nl)]).reshape(nl, B * L, D)
+    ek, ev = _rel(ctx_k, rk.detach()), _rel(ctx_v, rv.detach())
+    ((rk * dk.float()).sum() + (rv * dv.float()).sum()).backward()
+    ref_g = flatten_mapper_state({k: v.grad for k, v in p_o.items()})
+    eg = _rel(go, ref_g)
+    cos = torch.nn.functional.cosine_similarity(go.float().cpu(), ref_g, dim=0).item()
+    n_in = E * P2 + E
+    eg_in = _rel(go[-n_in:], ref_g[-n_in:])
+    print(f"[text legacy mapper drop={dropout}] ctx_k rel {ek:.3e} ctx_v rel {ev:.3e}; grad rel {eg:.3e} cos {cos:.6f}; "
+          f"input_layer grad rel {eg_in:.3e} |g_in| {ref_g[-n_in:].norm():.3e}")
+    assert ek < 5e-3 and ev < 5e-3
+    assert math.isfinite(eg) and eg < 3e-2 and cos > 0.999 and eg_in < 3e-2
+    # accumulate mode adds on top
+    eng.accumulate_grads = True
+    eng.backward()
+    torch.cuda.synchronize()
+    assert _rel(go, 2 * ref_g) < 3e-2

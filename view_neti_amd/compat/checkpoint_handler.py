@@ -124,7 +124,12 @@ class CheckpointHandler:
                            bypass_unconstrained=unconstrained, output_bypass_alpha=alpha,
                            placeholder_object_token=entry["placeholder_object_token"], cam_mins=cam_mins,
                            cam_maxs=cam_maxs, use_nested_dropout=mc.use_nested_dropout,
-                           nested_dropout_prob=mc.nested_dropout_prob)
+                           nested_dropout_prob=mc.nested_dropout_prob, arch_view_net=mc.arch_view_net,
+                           num_pe_time_anchors=mc.num_pe_time_anchors)
+            if m.legacy:
+                # the legacy frequencies are NOT seeded: the pickled encoder instance is their only record
+                # (checkpoint_handler.py:213-215 copies them over the freshly drawn ones as well)
+                m.encoder.w = entry["encoder"].w.detach().float().cpu().clone()
             state = dict(entry["state_dict"])
             missing = set(m.mapper_state()) ^ set(state)
             if missing:

@@ -105,7 +105,8 @@ class Coach:
             seed=parallel.data_seed(cfg.seed, self.rank), world_size=self.world, device=device,
             grad_accum=cfg.optim.gradient_accumulation_steps, hidden_object=first.hidden,
             unconstrained_object=m.bypass_unconstrained_object, unconstrained_view=m.bypass_unconstrained_view,
-            nested_dropout_prob=m.nested_dropout_prob if m.use_nested_dropout else 0.0, **kw)
+            nested_dropout_prob=m.nested_dropout_prob if m.use_nested_dropout else 0.0,
+            **first.engine_encoder_kwargs(), **kw)
         self.engine.set_lr(self.lr_schedule.lr(0))
         self.validator = None
         if cfg.eval.validation_prompts is not None and cfg.eval.validation_steps <= cfg.optim.max_train_steps \
@@ -224,9 +225,19 @@ class Coach:
 
     def _init_neti_mappers(self):
         cfg, m = self.cfg, self.cfg.model
-        if m.arch_view_net != 15 or m.arch_view_disable_tl:
-            raise NotImplementedError("the HIP engine implements the paper's arch_view_net=15 mappers "
-                                      "(set --model.arch_view_net 15 --model.arch_view_disable_tl False)")
+        legacy = m.arch_view_net <= 14
+        if legacy:
+            # the dataclass default (config.py:130): NeTIPositionalEncoding + anchor-initialised input_layer; the view
+            # side of that era needs `encode_phi`, which the reference never defines (neti_mapper.py:347-348)
+            if cfg.learnable_mode != 0:
+                raise NotImplementedError("arch_view_net <= 14 (legacy mappers) works for object mappers only "
+                                          "(learnable_mode 0); the view modes need --model.arch_view_net 15 "
+                                          "--model.arch_view_disable_tl False")
+            if int(m.use_positional_encoding_object) != 1:
+                raise NotImplementedError("legacy mapper: only use_positional_encoding_object = 1 (NeTIPositionalEncoding)")
+        elif m.arch_view_net != 15 or m.arch_view_disable_tl:
+            raise NotImplementedError("the HIP engine implements arch_view_net = 15 (with arch_view_disable_tl False, "
+                                      "neti_mapper.py:481-483) and the legacy object mapper of arch_view_net <= 14")
         if m.original_ti:
             raise NotImplementedError("original_ti (plain textual inversion baseline) is outside the NeTI hot path")
         if cfg.learnable_mode == 1:
@@ -243,7 +254,8 @@ class Coach:
                                           m.pe_sigmas, m.output_bypass_object, m.bypass_unconstrained_object,
                                           m.output_bypass_alpha_object, token,
                                           use_nested_dropout=m.use_nested_dropout,
-                                          nested_dropout_prob=m.nested_dropout_prob)
+                                          nested_dropout_prob=m.nested_dropout_prob, arch_view_net=m.arch_view_net,
+                                          num_pe_time_anchors=m.num_pe_time_anchors)
         view = None
         if cfg.learnable_mode in (2, 3):
             ds = self.train_dataset
@@ -277,7 +289,8 @@ class Coach:
         eng, D = self.engine, self.cfg.model.word_embedding_dim
         for tid, k in self.object_slot.items():
             obj = self.mapper_object_lookup[tid]
-            obj.load_state_dict(unflatten_mapper_state(eng.object_params(k).cpu(), 64, obj.hidden, 2 * D), strict=False)
+            obj.load_state_dict(unflatten_mapper_state(eng.object_params(k).cpu(), obj.enc_dim, obj.hidden, 2 * D,
+                                                       obj.pe_dim), strict=False)
         if self.mapper_view is not None and eng.view_params_flat().numel() > 0:
             self.mapper_view.load_state_dict(unflatten_mapper_state(eng.view_params_flat().cpu(), 64, 64, 2 * D),
                                              strict=False)

@@ -88,7 +88,8 @@ def load_inference(exp_dir, mapper_stem: str = "mapper-final", batch: int = 1, h
                   unconstrained_view=m.bypass_unconstrained_view)
     eng = InferenceEngine(sd, unet_w, dec_w, clip_w, batch, height, width, mo.mapper_state(), mo.encoder.w,
                           mo.norm_scale, m.output_bypass_alpha_object, hidden_object=mo.hidden,
-                          unconstrained_object=m.bypass_unconstrained_object, device=device, **kw)
+                          unconstrained_object=m.bypass_unconstrained_object, device=device,
+                          **mo.engine_encoder_kwargs(), **kw)
     pipe = InferencePipeline(eng, tok, sampler)
     pm = PromptManager(tok, placeholder_view_token_ids=view_ids, placeholder_object_token_ids=object_ids,
                        view_params_fn=cam_fn)

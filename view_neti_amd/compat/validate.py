@@ -55,7 +55,7 @@ class ValidationHandler:
             coach.sd, unet_w, vae_dec_w, clip_w, 1, h, w, None, first.encoder.w, first.norm_scale,
             m.output_bypass_alpha_object, hidden_object=first.hidden, unconstrained_object=m.bypass_unconstrained_object,
             device=eng.dev, params_object=eng.params[: eng.n_all_obj], object_slot=self.slot,
-            object_slot_stride=eng.n_obj, **kw)
+            object_slot_stride=eng.n_obj, **first.engine_encoder_kwargs(), **kw)
         self.pipeline = InferencePipeline(self.engine, coach.tokenizer, "dpm++2m")
         self.prompt_manager = PromptManager(
             coach.tokenizer, placeholder_view_token_ids=coach.placeholder_view_token_ids,

@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int MAXH = 128;  // max hidden width of the mapper MLP
+constexpr int MAXH = 192;  // max hidden width / encoding width of the mapper MLP (legacy path: 10 x 16 = 160 anchors)
 
 struct MapperParams {
   // offsets (in floats) into the flat parameter / gradient bucket, state_dict order:
@@ -53,14 +53,17 @@ __global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const 
                                                          const float* __restrict__ w_enc,
                                                          const float* __restrict__ hmask, float norm_scale,
                                                          float* __restrict__ word, float* __restrict__ bypass,
-                                                         float* __restrict__ save) {
+                                                         float* __restrict__ save,
+                                                         const float* __restrict__ enc_in) {
   __shared__ float enc[MAXH], z[MAXH], xh[MAXH], y[MAXH], a[MAXH], stat[2], red[4];
   const int r = blockIdx.x, tid = threadIdx.x;
   if (slot) params += (long long)slot[0] * slot_stride;  // which mapper of a multi-mapper bucket (device-side)
   const int E = mp.E, hd = mp.hd, D = mp.D;
   // per-row save area: enc[E] | xh1[hd] | a1[hd] | xh2[hd] | a2m[hd] | rstd1, rstd2, wnorm, pad
   float* sv = save + (long long)r * (E + 4 * hd + 4);
-  if (tid < E / 2) {
+  if (enc_in) {  // legacy mapper: the first-layer input is the output of its trainable input_layer (computed upstream)
+    if (tid < E) enc[tid] = enc_in[(long long)r * E + tid];
+  } else if (tid < E / 2) {
     float p = 0.f;
     for (int f = 0; f < nfeat; ++f) p += w_enc[tid * nfeat + f] * data[r * nfeat + f];
     enc[tid] = sinf(p);
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, c
                                                               const int* __restrict__ dword_rows, long long ld_src,
                                                               const float* __restrict__ dbypass,
                                                               const float* __restrict__ save,
-                                                              float* __restrict__ rowgrads) {
+                                                              float* __restrict__ rowgrads,
+                                                              float* __restrict__ denc) {
   __shared__ float dout[2048 + 64], part[4][MAXH], dz[MAXH], da[MAXH], red[4], st[2];
   const int r = blockIdx.x, tid = threadIdx.x;
   if (slot) params += (long long)slot[0] * slot_stride;
@@ -221,8 +225,81 @@ __global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, c
     st[1] = m2 / hd;
   }
   __syncthreads();
-  if (tid < hd) rg[OD + 2 * hd + tid] = sv[E + 4 * hd] * (da[tid] - st[0] - sv[E + tid] * st[1]);  // dz1
+  if (tid < hd) {
+    const float v = sv[E + 4 * hd] * (da[tid] - st[0] - sv[E + tid] * st[1]);
+    rg[OD + 2 * hd + tid] = v;  // dz1
+    dz[tid] = v;
+  }
+  if (denc) {  // legacy mapper: gradient w.r.t. the first layer's input, d enc[i] = sum_j W0[j][i] dz1[j]
+    __syncthreads();
+    if (tid < E) {
+      float s = 0.f;
+      for (int j = 0; j < hd; ++j) s += params[mp.w0 + j * E + tid] * dz[j];
+      denc[(long long)r * E + tid] = s;
+    }
+  }
 }
+
+// ---------------------------------------------------------------------------------------------
+// legacy mapper (arch_view_net <= 14): NeTIPositionalEncoding + the trainable input_layer
+//   v = cat[sin(w x), cos(w x)] / |.|  of x = (t, l) RAW (models/positional_encoding.py:23-41); |v| = sqrt(num_w)
+//   e = W_in v + b_in,  W_in [E][2*num_w]  (models/neti_mapper.py:155-163, :200-206)
+// pin layout: W_in [E][P2] | b_in [E]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float legacy_pe(const float* __restrict__ w_pe, int nw, int k, float t, float l, float inv) {
+  const int f = k < nw ? k : k - nw;
+  const float p = w_pe[2 * f] * t + w_pe[2 * f + 1] * l;
+  return (k < nw ? sinf(p) : cosf(p)) * inv;
+}
+
+__global__ __launch_bounds__(256) void legacy_input_fwd_kernel(const float* __restrict__ pin, const int* __restrict__ slot,
+                                                               long long slot_stride, const long long* __restrict__ t,
+                                                               const float* __restrict__ w_pe, float* __restrict__ enc_out,
+                                                               int nl, int Bn, int E, int P2) {
+  __shared__ float v[4096];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (slot) pin += (long long)slot[0] * slot_stride;
+  const int nw = P2 / 2;
+  const float tt = (float)t[r % Bn], ll = (float)(r / Bn), inv = rsqrtf((float)nw);
+  for (int k = tid; k < P2; k += 256) v[k] = legacy_pe(w_pe, nw, k, tt, ll, inv);
+  __syncthreads();
+  for (int o = wave; o < E; o += 4) {  // one wave per output: lanes stride the 2048 inputs (coalesced weight rows)
+    const float* wr = pin + (long long)o * P2;
+    float s = 0.f;
+    for (int k = lane; k < P2; k += 64) s += wr[k] * v[k];
+    s = wave_sum(s);
+    if (lane == 0) enc_out[(long long)r * E + o] = s + pin[(long long)E * P2 + o];
+  }
+}
+
+// d W_in[o][k] = sum_r denc[r][o] v_r[k],  d b_in[o] = sum_r denc[r][o]; one block per 256 consecutive k
+__global__ __launch_bounds__(256) void legacy_input_bwd_kernel(const long long* __restrict__ t, const float* __restrict__ w_pe,
+                                                               const float* __restrict__ denc, float* __restrict__ gin,
+                                                               const int* __restrict__ slot, long long slot_stride,
+                                                               int accumulate, int nl, int Bn, int E, int P2) {
+  extern __shared__ float vs[];  // [R][256]
+  const int R = nl * Bn, tid = threadIdx.x, k = blockIdx.x * 256 + tid, nw = P2 / 2;
+  if (slot) gin += (long long)slot[0] * slot_stride;
+  const float inv = rsqrtf((float)nw);
+  if (k < P2)
+    for (int r = 0; r < R; ++r) vs[r * 256 + tid] = legacy_pe(w_pe, nw, k, (float)t[r % Bn], (float)(r / Bn), inv);
+  __syncthreads();
+  if (k < P2) {
+    for (int o = 0; o < E; ++o) {
+      float s = 0.f;
+      for (int r = 0; r < R; ++r) s += denc[(long long)r * E + o] * vs[r * 256 + tid];
+      float* g = gin + (long long)o * P2 + k;
+      *g = accumulate ? *g + s : s;
+    }
+  }
+  if (blockIdx.x == 0 && tid < E) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += denc[(long long)r * E + tid];
+    float* g = gin + (long long)E * P2 + tid;
+    *g = accumulate ? *g + s : s;
+  }
+}
+
 
 // backward stage 2: one thread per parameter, summing the per-row outer products over R rows.
 __global__ __launch_bounds__(256) void mapper_bwd_reduce_kernel(MapperParams mp, int R,
@@ -631,14 +708,15 @@ extern "C" long long vneti_mapper_rowgrad_floats(int R, int hidden, int D, int h
 extern "C" int vneti_mapper_fwd(const float* params, const int* slot, long long slot_stride, const float* data,
                                 int nfeat, const float* w_enc,
                                 const float* hidden_mask, float norm_scale, float* word, float* bypass, float* save,
-                                int R, int enc_dim, int hidden, int D, int has_bypass, void* stream) {
+                                int R, int enc_dim, int hidden, int D, int has_bypass, const float* enc_in,
+                                void* stream) {
   MapperParams mp;
   VN_REQUIRE(fill_mp(mp, enc_dim, hidden, D, has_bypass) > 0, "mapper_fwd: unsupported dims E=%d hd=%d D=%d",
              enc_dim, hidden, D);
-  VN_REQUIRE(params && data && w_enc && word && save && R > 0 && nfeat > 0 && (!has_bypass || bypass),
+  VN_REQUIRE(params && word && save && R > 0 && (enc_in || (data && w_enc && nfeat > 0)) && (!has_bypass || bypass),
              "mapper_fwd: bad arguments");
   hipLaunchKernelGGL(mapper_fwd_kernel, dim3(R), dim3(256), 0, ST, mp, params, slot, slot_stride, data, nfeat, w_enc, hidden_mask,
-                     norm_scale, word, bypass, save);
+                     norm_scale, word, bypass, save, enc_in);
   return vneti_check_launch("mapper_fwd");
 }
 
@@ -647,18 +725,49 @@ extern "C" int vneti_mapper_bwd(const float* params, const int* slot, long long 
                                 const float* dword_src, const int* dword_rows, long long ld_src,
                                 const float* dbypass, const float* save, float* rowgrads, float* grads,
                                 int accumulate, int R, int enc_dim, int hidden, int D, int has_bypass,
-                                void* stream) {
+                                float* denc, void* stream) {
   MapperParams mp;
   int np = fill_mp(mp, enc_dim, hidden, D, has_bypass);
   VN_REQUIRE(np > 0, "mapper_bwd: unsupported dims E=%d hd=%d D=%d", enc_dim, hidden, D);
   VN_REQUIRE(params && word && dword_src && dword_rows && save && rowgrads && grads && R > 0,
              "mapper_bwd: bad arguments");
   hipLaunchKernelGGL(mapper_bwd_rows_kernel, dim3(R), dim3(256), 0, ST, mp, params, slot, slot_stride, hidden_mask, norm_scale, word,
-                     dword_src, dword_rows, ld_src, dbypass, save, rowgrads);
+                     dword_src, dword_rows, ld_src, dbypass, save, rowgrads, denc);
   hipLaunchKernelGGL(mapper_bwd_reduce_kernel, dim3(cdiv(np, 256)), dim3(256), 0, ST, mp, R, save,
                      (const float*)rowgrads, grads, np, accumulate, slot, slot_stride);
   return vneti_check_launch("mapper_bwd");
 }
+
+extern "C" long long vneti_mapper_legacy_input_params(int enc_dim, int pe_dim) { return (long long)enc_dim * pe_dim + enc_dim; }
+
+extern "C" int vneti_mapper_legacy_input_fwd(const float* params_in, const int* slot, long long slot_stride,
+                                             const void* timesteps_i64, const float* w_pe, float* enc_out, int nl, int Bn,
+                                             int enc_dim, int pe_dim, void* stream) {
+  VN_REQUIRE(params_in && timesteps_i64 && w_pe && enc_out && nl > 0 && Bn > 0, "mapper_legacy_input_fwd: bad arguments");
+  VN_REQUIRE(enc_dim > 0 && enc_dim <= MAXH && pe_dim > 0 && pe_dim <= 4096 && pe_dim % 2 == 0,
+             "mapper_legacy_input_fwd: unsupported dims E=%d P=%d", enc_dim, pe_dim);
+  hipLaunchKernelGGL(legacy_input_fwd_kernel, dim3(nl * Bn), dim3(256), 0, ST, params_in, slot, slot_stride,
+                     (const long long*)timesteps_i64, w_pe, enc_out, nl, Bn, enc_dim, pe_dim);
+  return vneti_check_launch("mapper_legacy_input_fwd");
+}
+
+extern "C" int vneti_mapper_legacy_input_bwd(const void* timesteps_i64, const float* w_pe, const float* denc, float* grads_in,
+                                             const int* slot, long long slot_stride, int accumulate, int nl, int Bn,
+                                             int enc_dim, int pe_dim, void* stream) {
+  VN_REQUIRE(timesteps_i64 && w_pe && denc && grads_in && nl > 0 && Bn > 0, "mapper_legacy_input_bwd: bad arguments");
+  VN_REQUIRE(enc_dim > 0 && enc_dim <= 256 && pe_dim > 0 && pe_dim % 2 == 0 && nl * Bn <= 128,
+             "mapper_legacy_input_bwd: unsupported dims E=%d P=%d R=%d", enc_dim, pe_dim, nl * Bn);
+  const size_t lds = (size_t)nl * Bn * 256 * sizeof(float);
+  static bool lds_opt_in = false;  // > 64 KiB of dynamic LDS needs the attribute (set once, outside any capture: the
+  if (!lds_opt_in) {               //   first call of an engine is an eager warm-up launch)
+    hipFuncSetAttribute((const void*)legacy_input_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4);
+    lds_opt_in = true;
+  }
+  hipLaunchKernelGGL(legacy_input_bwd_kernel, dim3(cdiv(pe_dim, 256)), dim3(256), lds, ST, (const long long*)timesteps_i64,
+                     w_pe, denc, grads_in, slot, slot_stride, accumulate, nl, Bn, enc_dim, pe_dim);
+  return vneti_check_launch("mapper_legacy_input_bwd");
+}
+
 
 extern "C" int vneti_text_embed(const float* tok_emb, const float* pos_emb, const void* ids, const int* pos_obj,
                                 const float* word_obj, const int* pos_view, const float* word_view, float* X, int nl,

@@ -74,7 +74,8 @@ class InferenceEngine:
                  unconstrained_object: bool = False, unconstrained_view: bool = False, hidden_object: int = 64,
                  device: str = "cuda", params_object: Optional[torch.Tensor] = None,
                  params_view: Optional[torch.Tensor] = None, object_slot: Optional[torch.Tensor] = None,
-                 object_slot_stride: int = 0):
+                 object_slot_stride: int = 0, legacy_pe_object: Optional[torch.Tensor] = None,
+                 enc_dim_object: int = 64):
         """params_object / params_view: flat device buckets to ALIAS instead of copying the state dicts (validation
         during training reads the live parameters); object_slot (+stride) picks one mapper of a multi-object bucket."""
         self.cfg = cfg
@@ -93,9 +94,11 @@ class InferenceEngine:
         self.ctx_k = torch.zeros((nl, B * L, D), dtype=torch.float16, device=device)
         self.ctx_v = torch.zeros_like(self.ctx_k)
         po = params_object if params_object is not None else flatten_mapper_state(mapper_object).to(device)
-        mo = MapperState(po, w_enc_object.to(device).float().contiguous(), norm_scale_object, alpha_object,
-                         hidden=hidden_object, unconstrained=unconstrained_object, slot=object_slot,
-                         slot_stride=object_slot_stride)
+        mo = MapperState(po, w_enc_object.to(device).float().contiguous() if legacy_pe_object is None else None,
+                         norm_scale_object, alpha_object, hidden=hidden_object, enc_dim=enc_dim_object,
+                         unconstrained=unconstrained_object, slot=object_slot, slot_stride=object_slot_stride,
+                         legacy_w_pe=(legacy_pe_object.to(device).float().contiguous()
+                                      if legacy_pe_object is not None else None))
         mv = None
         if mapper_view is not None or params_view is not None:
             pv = params_view if params_view is not None else flatten_mapper_state(mapper_view).to(device)

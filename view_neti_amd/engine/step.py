@@ -48,7 +48,8 @@ class TrainStepEngine:
                  seed: int = 0, world_size: int = 1, device_rng: bool = True, device: str = "cuda",
                  need_backward: bool = True, grad_accum: int = 1, overlap: bool = True,
                  unconstrained_object: bool = False, unconstrained_view: bool = False,
-                 nested_dropout_prob: float = 0.0, hidden_object: int = 64):
+                 nested_dropout_prob: float = 0.0, hidden_object: int = 64,
+                 legacy_pe_object: Optional[torch.Tensor] = None, enc_dim_object: int = 64):
         """mapper_object: one mapper state_dict, or a list of them (learnable_mode 3: one object mapper per
         scene, `mapper_object_lookup`, training/coach.py:505-552) — `set_batch(object_index=k)` picks the one
         the batch trains."""
@@ -87,10 +88,16 @@ class TrainStepEngine:
         multi = self.n_objects > 1
         # RNG state first: nested dropout draws from it
         self.rng_state = torch.tensor([seed & 0x7FFFFFFF, 0], dtype=torch.int32, device=device)
-        mo = MapperState(self.params[:n_all_obj], w_enc_object.to(device).float().contiguous(), norm_scale_object,
-                         alpha_object, hidden=hidden_object, unconstrained=unconstrained_object,
+        # legacy_pe_object: the [1024][2] frequencies of a legacy (arch_view_net <= 14) object mapper; its state dict then
+        # carries input_layer.* and enc_dim_object = anchors * layers = 160 (models/neti_mapper.py:90-163)
+        mo = MapperState(self.params[:n_all_obj],
+                         w_enc_object.to(device).float().contiguous() if legacy_pe_object is None else None,
+                         norm_scale_object, alpha_object, hidden=hidden_object, enc_dim=enc_dim_object,
+                         unconstrained=unconstrained_object,
                          nested_dropout_prob=nested_dropout_prob, slot=self.obj_slot if multi else None,
-                         slot_stride=self.n_obj if multi else 0)
+                         slot_stride=self.n_obj if multi else 0,
+                         legacy_w_pe=(legacy_pe_object.to(device).float().contiguous()
+                                      if legacy_pe_object is not None else None))
         mv, gv = None, None
         if mapper_view is not None:
             if flat_v is not None:

@@ -27,11 +27,15 @@ from .schedule import Schedule, rup
 
 
 class MapperState:
-    """Flat f32 parameter bucket of one NeTIMapper (arch_view_net=15) + its Fourier frequencies."""
+    """Flat f32 parameter bucket of one NeTIMapper + its encoder frequencies: the Fourier `w_enc` of the paper's
+    arch_view_net = 15, or (`legacy_w_pe` given) the 1024 x 2 frequencies of the legacy NeTIPositionalEncoding, in
+    which case the bucket ends with the trainable input_layer [enc_dim][2*num_w] + bias and enc_dim = 10*16 = 160."""
 
-    def __init__(self, params: torch.Tensor, w_enc: torch.Tensor, norm_scale: Optional[float], alpha: float,
+    def __init__(self, params: torch.Tensor, w_enc: Optional[torch.Tensor], norm_scale: Optional[float], alpha: float,
                  hidden: int = 64, enc_dim: int = 64, unconstrained: bool = False, nested_dropout_prob: float = 0.0,
-                 slot: Optional[torch.Tensor] = None, slot_stride: int = 0):
+                 slot: Optional[torch.Tensor] = None, slot_stride: int = 0, legacy_w_pe: Optional[torch.Tensor] = None):
+        self.legacy_w_pe = legacy_w_pe  # device f32 [num_w][2]; None = Fourier path
+        self.pe_dim = 2 * legacy_w_pe.shape[0] if legacy_w_pe is not None else 0
         self.params = params            # flat bucket (of `slot_stride`-spaced mappers when slot is given)
         self.w_enc = w_enc
         self.norm_scale = norm_scale
@@ -46,17 +50,22 @@ class MapperState:
 
 def flatten_mapper_state(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
     """state_dict (reference key names, checkpoint_handler.py:57-97) -> flat bucket in the order the
-    kernels expect."""
+    kernels expect; the legacy mapper's input_layer (neti_mapper.py:155-163) goes LAST."""
     keys = ["net.0.weight", "net.0.bias", "net.1.weight", "net.1.bias", "net.3.weight", "net.3.bias",
             "net.4.weight", "net.4.bias", "output_layer.0.weight", "output_layer.0.bias"]
+    if "input_layer.weight" in sd:
+        keys += ["input_layer.weight", "input_layer.bias"]
     return torch.cat([sd[k].reshape(-1).float() for k in keys])
 
 
-def unflatten_mapper_state(flat: torch.Tensor, enc_dim: int, hidden: int, out_dim: int) -> Dict[str, torch.Tensor]:
+def unflatten_mapper_state(flat: torch.Tensor, enc_dim: int, hidden: int, out_dim: int, pe_dim: int = 0
+                           ) -> Dict[str, torch.Tensor]:
     shapes = [("net.0.weight", (hidden, enc_dim)), ("net.0.bias", (hidden,)), ("net.1.weight", (hidden,)),
               ("net.1.bias", (hidden,)), ("net.3.weight", (hidden, hidden)), ("net.3.bias", (hidden,)),
               ("net.4.weight", (hidden,)), ("net.4.bias", (hidden,)), ("output_layer.0.weight", (out_dim, hidden)),
               ("output_layer.0.bias", (out_dim,))]
+    if pe_dim:
+        shapes += [("input_layer.weight", (enc_dim, pe_dim)), ("input_layer.bias", (enc_dim,))]
     out, o = {}, 0
     for k, shp in shapes:
         n = 1
@@ -207,10 +216,23 @@ class TextEngine(Schedule):
         self.bo = self._mapper_bufs(mo, 2)
         if self.hidden_mask_obj is not None or self.hidden_mask_view is not None:
             f.append(self._draw_masks)
-        f.append(partial(ops.mapper_inputs, self.timesteps, None, self.bo["data"], nl, B))
-        f.append(lambda: ops.mapper_fwd(mo.params, self.bo["data"], mo.w_enc, self.hidden_mask_obj, mo.norm_scale,
-                                        self.bo["word"], self.bo["byp"], self.bo["save"], R, mo.enc_dim, mo.hidden, D,
-                                        True, mo.slot, mo.slot_stride))
+        if mo.legacy_w_pe is not None:
+            # legacy object mapper (arch_view_net <= 14): NeTIPositionalEncoding of the raw (t, l) -> trainable input_layer
+            # (the tail of the bucket) -> the same MLP kernels fed through `enc_in`
+            self.n_std_obj = ops.mapper_num_params(mo.enc_dim, mo.hidden, D)
+            self.bo["enc"] = self._buf((R, mo.enc_dim), torch.float32)
+            self.bo["denc"] = self._buf((R, mo.enc_dim), torch.float32)
+            f.append(lambda: ops.mapper_legacy_input_fwd(mo.params[self.n_std_obj:], self.timesteps, mo.legacy_w_pe,
+                                                         self.bo["enc"], nl, B, mo.enc_dim, mo.pe_dim, mo.slot,
+                                                         mo.slot_stride))
+            f.append(lambda: ops.mapper_fwd(mo.params, None, None, self.hidden_mask_obj, mo.norm_scale, self.bo["word"],
+                                            self.bo["byp"], self.bo["save"], R, mo.enc_dim, mo.hidden, D, True, mo.slot,
+                                            mo.slot_stride, enc_in=self.bo["enc"]))
+        else:
+            f.append(partial(ops.mapper_inputs, self.timesteps, None, self.bo["data"], nl, B))
+            f.append(lambda: ops.mapper_fwd(mo.params, self.bo["data"], mo.w_enc, self.hidden_mask_obj, mo.norm_scale,
+                                            self.bo["word"], self.bo["byp"], self.bo["save"], R, mo.enc_dim, mo.hidden,
+                                            D, True, mo.slot, mo.slot_stride))
         self.bv = None
         if self.mv is not None:
             mv = self.mv
@@ -312,7 +334,11 @@ class TextEngine(Schedule):
         bw.append(lambda: ops.mapper_bwd(mo.params, self.hidden_mask_obj, mo.norm_scale, self.bo["word"], self.dx0,
                                          self.rows_obj, D, self.bo["dbyp"], self.bo["save"], self.bo["rowg"], self.go,
                                          self.accumulate_grads, R, mo.enc_dim, mo.hidden, D, True, mo.slot,
-                                         mo.slot_stride))
+                                         mo.slot_stride, denc=self.bo.get("denc")))
+        if mo.legacy_w_pe is not None:
+            bw.append(lambda: ops.mapper_legacy_input_bwd(self.timesteps, mo.legacy_w_pe, self.bo["denc"],
+                                                          self.go[self.n_std_obj:], self.accumulate_grads, self.nl, self.B,
+                                                          mo.enc_dim, mo.pe_dim, mo.slot, mo.slot_stride))
         if self.train_view:
             mv = self.mv
             bw.append(lambda: ops.mapper_bwd(mv.params, self.hidden_mask_view, mv.norm_scale, self.bv["word"], self.dx0,

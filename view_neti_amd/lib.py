@@ -11,7 +11,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libvneti_hip.so")
+# VNETI_LIB_PATH: kernel-development aid (A/B a lab build of the same ABI); the product path is the in-tree library
+SO_PATH = os.environ.get("VNETI_LIB_PATH") or os.path.join(_HERE, "csrc", "libvneti_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vneti.h")
 
 _lib = None
@@ -164,9 +165,11 @@ SIGNATURES = {
     "adamw_segments": [c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp],
     "nested_dropout_mask": [c_vp, c_int, c_int, c_int, c_f, c_vp, C.c_uint, c_vp],
     "mapper_fwd": [c_vp, c_vp, c_ll, c_vp, c_int, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                   c_int, c_vp],
+                   c_int, c_vp, c_vp],
     "mapper_bwd": [c_vp, c_vp, c_ll, c_vp, c_f, c_vp, c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
-                   c_int, c_int, c_int, c_int, c_vp],
+                   c_int, c_int, c_int, c_int, c_vp, c_vp],
+    "mapper_legacy_input_fwd": [c_vp, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "mapper_legacy_input_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_vp],
     "text_embed": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "text_final_fwd": [c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp,
                        c_int, c_int, c_int, c_int, c_vp],
@@ -183,6 +186,7 @@ LL_FUNCS = {
     "mapper_num_params": [c_int] * 4,
     "mapper_save_floats": [c_int] * 3,
     "mapper_rowgrad_floats": [c_int] * 4,
+    "mapper_legacy_input_params": [c_int] * 2,
 }
 
 

@@ -288,17 +288,32 @@ def mapper_rowgrad_floats(R, hidden, D, has_bypass=True):
 
 
 def mapper_fwd(params, data, w_enc, hidden_mask, norm_scale, word, bypass, save, R, enc_dim, hidden, D, has_bypass,
-               slot=None, slot_stride=0):
-    _l.call("mapper_fwd", _p(params), _p(slot), slot_stride, _p(data), data.shape[1], _p(w_enc), _p(hidden_mask),
+               slot=None, slot_stride=0, enc_in=None):
+    _l.call("mapper_fwd", _p(params), _p(slot), slot_stride, _p(data), data.shape[1] if data is not None else 0,
+            _p(w_enc), _p(hidden_mask),
             norm_scale if norm_scale is not None else -1.0, _p(word), _p(bypass), _p(save), R, enc_dim, hidden, D,
-            1 if has_bypass else 0, stream())
+            1 if has_bypass else 0, _p(enc_in), stream())
 
 
 def mapper_bwd(params, hidden_mask, norm_scale, word, dword_src, dword_rows, ld_src, dbypass, save, rowgrads, grads,
-               accumulate, R, enc_dim, hidden, D, has_bypass, slot=None, slot_stride=0):
+               accumulate, R, enc_dim, hidden, D, has_bypass, slot=None, slot_stride=0, denc=None):
     _l.call("mapper_bwd", _p(params), _p(slot), slot_stride, _p(hidden_mask), norm_scale if norm_scale is not None else -1.0, _p(word),
             _p(dword_src), _p(dword_rows), ld_src, _p(dbypass), _p(save), _p(rowgrads), _p(grads),
-            1 if accumulate else 0, R, enc_dim, hidden, D, 1 if has_bypass else 0, stream())
+            1 if accumulate else 0, R, enc_dim, hidden, D, 1 if has_bypass else 0, _p(denc), stream())
+
+
+def mapper_legacy_input_params(enc_dim, pe_dim):
+    return _l.call_ll("mapper_legacy_input_params", enc_dim, pe_dim)
+
+
+def mapper_legacy_input_fwd(params_in, timesteps, w_pe, enc_out, nl, Bn, enc_dim, pe_dim, slot=None, slot_stride=0):
+    _l.call("mapper_legacy_input_fwd", _p(params_in), _p(slot), slot_stride, _p(timesteps), _p(w_pe), _p(enc_out), nl, Bn,
+            enc_dim, pe_dim, stream())
+
+
+def mapper_legacy_input_bwd(timesteps, w_pe, denc, grads_in, accumulate, nl, Bn, enc_dim, pe_dim, slot=None, slot_stride=0):
+    _l.call("mapper_legacy_input_bwd", _p(timesteps), _p(w_pe), _p(denc), _p(grads_in), _p(slot), slot_stride,
+            1 if accumulate else 0, nl, Bn, enc_dim, pe_dim, stream())
 
 
 def text_embed(tok_emb, pos_emb, ids, pos_obj, word_obj, pos_view, word_view, X, nl, Bn, L, D):
