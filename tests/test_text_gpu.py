@@ -180,3 +180,45 @@ def test_text_engine_legacy_object_mapper(dropout):
     eng.backward()
     torch.cuda.synchronize()
     assert _rel(go, 2 * ref_g) < 3e-2
+
+
+def test_module_call_protocol_text_encoder():
+    """Seam B: `text_encoder(batch=NeTIBatch)` served by the HIP engine — the reference's calling pattern
+    (one call per UNet layer, `[0]` of both returned outputs; training/coach.py:289-305) against the oracle's
+    restatement of NeTICLIPTextTransformer.forward, which g7_text_encoder_bypass pins to the real module."""
+    from oracle import sd_ref as R
+    from utils.types import NeTIBatch
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.compat.neti_clip_text_encoder import HipNeTICLIPTextModel
+    from view_neti_amd.compat.neti_modules import NeTIMapper
+    cfg = sc.tiny().clip
+    D, L, B = cfg.hidden_size, cfg.max_positions, 2
+    w = synth.clip_weights(cfg)
+    wr = {k: (v.half().float() if (k.endswith("weight") and v.dim() == 2 and "embedding" not in k) else v)
+          for k, v in w.items()}
+    ph = cfg.vocab_size - 3
+    torch.manual_seed(4)
+    mapper = NeTIMapper("object", D, 64, 0.4, output_bypass_alpha=0.2, placeholder_object_token="<obj>")
+    with torch.no_grad():
+        for prm in mapper.parameters():
+            prm.add_(0.1 * torch.randn(prm.shape))
+    enc = HipNeTICLIPTextModel(cfg, wr)
+    enc.text_model.embeddings.set_mapper({ph: mapper}, None)
+    assert enc.get_input_embeddings().weight.shape == (cfg.vocab_size, D)
+    ids = synth.input_ids(B, ph, cfg.vocab_size, L)
+    t = torch.tensor([17, 803])
+    sd = {k: v.detach() for k, v in mapper.mapper_state().items()}
+    for layer in (0, 7, 15):
+        batch = NeTIBatch(input_ids=ids, input_ids_placeholder_object=torch.full((B,), ph),
+                          input_ids_placeholder_view=torch.full((B,), -1), timesteps=t,
+                          unet_layers=torch.full((B,), layer))
+        out, out_b = enc(batch=batch)
+        word, byp = R.mapper_forward(sd, mapper.encoder.w, t, torch.full((B,), float(layer)), 0.4)
+        ref, ref_b = R.neti_text_encoder(wr, cfg, ids, torch.full((B,), ph), word, byp, False, 0.2)
+        e0, e1 = _rel(out[0], ref), _rel(out_b[0], ref_b)
+        print(f"[module-call protocol layer {layer}] last_hidden_state rel {e0:.2e}, with bypass rel {e1:.2e}")
+        assert out[0].shape == (B, L, D) and e0 < 5e-3 and e1 < 5e-3
+        assert torch.equal(out.last_hidden_state, out[0]) and out.pooler_output.shape == (B, D)
+    # the plain input_ids= path (negative prompt, sd_pipeline_call.py:35-39): no bypass variant
+    plain, none = enc(input_ids=ids)
+    assert none is None and _rel(plain[0], R.clip_plain(wr, cfg, ids)) < 5e-3
