@@ -106,6 +106,10 @@ typedef struct vneti_gemm_desc {
                  pre-activation [M][2N]; C is [M][2N] in the same interleaved layout and receives
                  d_h = d * gelu(g), d_g = d * h * gelu'(g); the [M][N] GEMM result itself is not stored. */
   int geglu;
+  /* K order of an implicit convolution (B must be packed to match): 0 = (tap, channel); 1 = (64-channel chunk, tap,
+     channel in chunk): the nine taps of a chunk are consecutive k-steps, so the im2col re-reads of an input pixel
+     hit L1/L2 instead of coming back after a whole channel sweep. */
+  int conv_korder;
 } vneti_gemm_desc;
 
 int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream);

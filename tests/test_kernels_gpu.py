@@ -246,12 +246,15 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
+@pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
 @pytest.mark.parametrize("case", ["s1", "s2p1", "s2vae", "ups"])
 @pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 101, 103])
-def test_conv3x3_fwd(case, hint):
+def test_conv3x3_fwd(case, hint, korder):
+    """both K orders of the implicit GEMM (vneti_gemm_desc.conv_korder): (tap, channel) and (64-channel chunk, tap,
+    channel); two chunks so that the orders really differ"""
     ops = _ops()
     from view_neti_amd import packing
-    Bn, Ci, Co, H, W = 2, 64, 128, 12, 20
+    Bn, Ci, Co, H, W = 2, 128, 128, 12, 20
     x = rnd(Bn, Ci, H, W, seed=11)
     w = rnd(Co, Ci, 3, 3, scale=1 / math.sqrt(9 * Ci), seed=12)
     bias = rnd(Co, seed=13, dtype=torch.float32)
@@ -270,14 +273,17 @@ def test_conv3x3_fwd(case, hint):
         conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=2 * H, Wo=2 * W, stride=1, pad_t=1, pad_l=1, ups=1, ldx=Ci)
     Ho, Wo = ref.shape[2], ref.shape[3]
     out = torch.zeros(Bn * Ho * Wo, Co, dtype=torch.float16, device=DEV)
-    ops.gemm(_nhwc(x).to(DEV), packing.conv3x3_fwd(w).to(DEV), out, bias=bias.to(DEV), conv=conv,
+    conv["korder"] = korder
+    ops.gemm(_nhwc(x).to(DEV), packing.conv3x3_fwd(w, cm=bool(korder)).to(DEV), out, bias=bias.to(DEV), conv=conv,
              M=Bn * Ho * Wo, tile_hint=hint)
     torch.cuda.synchronize()
-    check(f"conv {case} hint{hint}", out.view(Bn, Ho, Wo, Co), _nhwc(ref), 2e-3)
+    check(f"conv {case} hint{hint} korder{korder}", out.view(Bn, Ho, Wo, Co), _nhwc(ref), 2e-3)
 
 
+@pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
+@pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("stride,vae", [(1, False), (2, False), (2, True)])
-def test_conv3x3_dgrad(stride, vae):
+def test_conv3x3_dgrad(stride, vae, split, korder):
     ops = _ops()
     from view_neti_amd import packing
     Bn, Ci, Co, H, W = 2, 64, 128, 12, 20
@@ -293,10 +299,12 @@ def test_conv3x3_dgrad(stride, vae):
     y.backward(dy.float())
     Ho, Wo = y.shape[2], y.shape[3]
     dx = torch.zeros(Bn * H * W, Ci, dtype=torch.float16, device=DEV)
-    conv = dict(mode=2, Hi=Ho, Wi=Wo, Ci=Co, Ho=H, Wo=W, stride=stride, pad_t=pt, pad_l=pt, ups=0, ldx=Co)
-    ops.gemm(_nhwc(dy).to(DEV), packing.conv3x3_dgrad(w).to(DEV), dx, conv=conv, M=Bn * H * W)
+    conv = dict(mode=2, Hi=Ho, Wi=Wo, Ci=Co, Ho=H, Wo=W, stride=stride, pad_t=pt, pad_l=pt, ups=0, ldx=Co, korder=korder)
+    ws = torch.empty(4 * Bn * H * W * Ci, dtype=torch.float32, device=DEV)
+    ops.gemm(_nhwc(dy).to(DEV), packing.conv3x3_dgrad(w, cm=bool(korder)).to(DEV), dx, conv=conv, M=Bn * H * W,
+             workspace=ws, split_k=split, tile_hint=3)
     torch.cuda.synchronize()
-    check(f"conv dgrad s{stride} vae={vae}", dx.view(Bn, H, W, Ci), _nhwc(x.grad), 2e-3)
+    check(f"conv dgrad s{stride} vae={vae} split{split} korder{korder}", dx.view(Bn, H, W, Ci), _nhwc(x.grad), 2e-3)
 
 
 def test_im2col_small_and_conv_in():

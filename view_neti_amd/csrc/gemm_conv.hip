@@ -58,6 +58,7 @@ struct GemmArgs {
   int conv_mode;  // 0 plain, 1 forward gather, 2 transposed gather (dgrad)
   int Hi, Wi, Ci, Ho, Wo, stride, pad_t, pad_l, ups;
   int ldx2;  // pixel stride in bytes
+  int korder;  // 0: K = (tap, ci); 1: K = (ci / 64, tap, ci % 64)
   int tiles_m, tiles_n;
 };
 
@@ -224,9 +225,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     bool recompute = first;
     int dy = 0, dx = 0, tapoff = 0;
     if (g.conv_mode != 0) {
-      const int tap = k0 / g.Ci;
-      const int ci0 = k0 - tap * g.Ci;
-      recompute = recompute || ci0 == 0;
+      int tap, ci0;
+      if (g.korder) {  // chunk-major: consecutive k-steps are the nine taps of one 64-channel chunk
+        const int chunk = kt / 9;
+        tap = kt - chunk * 9;
+        ci0 = chunk << 6;
+        recompute = true;
+      } else {
+        tap = k0 / g.Ci;
+        ci0 = k0 - tap * g.Ci;
+        recompute = recompute || ci0 == 0;
+      }
       if (recompute) {
         dy = tap / 3;
         dx = tap - dy * 3;
@@ -800,6 +809,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     g.pad_l = d->pad_l;
     g.ups = d->ups;
     g.ldx2 = (int)(d->ldx * 2);
+    g.korder = d->conv_korder ? 1 : 0;
     long long nb = d->M / (d->Ho * d->Wo);
     a_bytes = nb * d->Hi * d->Wi * d->ldx * 2;
   }

@@ -313,7 +313,7 @@ class Schedule:
 
     def _conv_desc(self, Hi, Wi, Ci, Ho, Wo, stride, pad, ups, ldx, mode=1):
         return dict(mode=mode, Hi=Hi, Wi=Wi, Ci=Ci, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad, pad_l=pad, ups=ups,
-                    ldx=ldx)
+                    ldx=ldx, korder=1 if packing.KORDER_CM else 0)
 
     def _resnet(self, x: T, cin, cout, name, w, out_view, h, wd, need_dx=True):
         """ResnetBlock2D: GN+SiLU -> conv1 (+ time-embedding row add) -> GN+SiLU -> conv2 + shortcut."""

@@ -53,6 +53,7 @@ class GemmDesc(C.Structure):
         ("C2", c_vp), ("ldc2", c_ll), ("act2", c_int),
         ("gn_sums", c_vp), ("gn_hw", c_int), ("gn_cpg", c_int), ("gn_groups", c_int), ("gn_slots", c_int),
         ("geglu", c_int),
+        ("conv_korder", c_int),
     ]
 
 

@@ -62,6 +62,7 @@ def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alp
         d.conv_mode = conv["mode"]
         for k in ("Hi", "Wi", "Ci", "Ho", "Wo", "stride", "pad_t", "pad_l", "ups", "ldx"):
             setattr(d, k, int(conv.get(k, 0)))
+        d.conv_korder = int(conv.get("korder", 0))
     d.batch = batch
     d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
     d.bias = _p(bias)

@@ -10,19 +10,38 @@ GEGLU projection [2*F][in] (rows 0..F-1 = h, F..2F-1 = gate) -> rows interleaved
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
+# K order of the implicit-GEMM convolutions (vneti_gemm_desc.conv_korder).  0: (tap, channel) — a k-step walks the
+# channels of one tap, so the nine re-reads of an input pixel are a whole channel sweep apart (>= 160 KB per block, past
+# the XCD's L2 at 32 blocks per XCD).  1: (64-channel chunk, tap, channel-in-chunk) — the nine taps of a chunk are
+# consecutive k-steps and re-read the same few KB straight from L1/L2.  Only for channel counts that are multiples of
+# 64 (the others go through vneti_im2col3x3_small and keep the tap-major order its output has).
+KORDER_CM = os.environ.get("VNETI_CONV_KORDER", "1") == "1"
 
-def conv3x3_fwd(w: torch.Tensor) -> torch.Tensor:
+
+def _chunk_major(m: torch.Tensor, n_out: int, c: int) -> torch.Tensor:
+    """[n_out][9][c] -> [n_out][c/64][9][64] flattened"""
+    return m.reshape(n_out, 9, c // 64, 64).permute(0, 2, 1, 3).reshape(n_out, 9 * c).contiguous()
+
+
+def conv3x3_fwd(w: torch.Tensor, cm=None) -> torch.Tensor:
+    """cm: chunk-major K order (None = the module default KORDER_CM); needs Ci % 64 == 0"""
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
-    return w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    m = w.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    cm = KORDER_CM if cm is None else cm
+    return _chunk_major(m, co, ci) if cm and ci % 64 == 0 else m
 
 
-def conv3x3_dgrad(w: torch.Tensor) -> torch.Tensor:
+def conv3x3_dgrad(w: torch.Tensor, cm=None) -> torch.Tensor:
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
-    return w.permute(1, 2, 3, 0).reshape(ci, 9 * co).contiguous()
+    m = w.permute(1, 2, 3, 0).reshape(ci, 9 * co).contiguous()
+    cm = KORDER_CM if cm is None else cm
+    return _chunk_major(m, ci, co) if cm and co % 64 == 0 else m
 
 
 def pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
