@@ -199,7 +199,8 @@ def test_gemm_geglu_epilogues(hint, M, C):
     (hg[:, :F4] * F.gelu(hg[:, F4:]) * d).sum().backward()
     check(f"geglu bwd hint{hint}", dp, hg.grad[:, idx], 2e-3)
     with pytest.raises(RuntimeError, match="split_k"):
-        ops.gemm(x.to(DEV), packing.geglu_interleave(W).to(DEV), p, out2=gg, geglu=1, split_k=2, tile_hint=3)
+        ops.gemm(x.to(DEV), packing.geglu_interleave(W).to(DEV), p, out2=gg, geglu=1, split_k=2, tile_hint=3,
+                 workspace=torch.empty(2 * M * 2 * F4, dtype=torch.float32, device=DEV))
 
 
 @pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9])

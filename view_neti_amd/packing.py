@@ -19,7 +19,9 @@ import torch
 # the XCD's L2 at 32 blocks per XCD).  1: (64-channel chunk, tap, channel-in-chunk) — the nine taps of a chunk are
 # consecutive k-steps and re-read the same few KB straight from L1/L2.  Only for channel counts that are multiples of
 # 64 (the others go through vneti_im2col3x3_small and keep the tap-major order its output has).
-KORDER_CM = os.environ.get("VNETI_CONV_KORDER", "1") == "1"
+# Measured (r02, bench A/B in one box): chunk-major is SLOWER on the step, 32.8 vs 31.8 ms — every k-step recomputes the
+# gather addresses and the autotuner falls back to smaller tiles; the L2 re-reads were not the limiter.  Kept switchable.
+KORDER_CM = os.environ.get("VNETI_CONV_KORDER", "0") == "1"
 
 
 def _chunk_major(m: torch.Tensor, n_out: int, c: int) -> torch.Tensor:
