@@ -7,7 +7,7 @@ B, H, N, D = 4, 8, int(os.environ.get("N", 4096)), int(os.environ.get("D", 40))
 Nk = int(os.environ.get("NK", N))
 C = H * D
 dev = "cuda"
-ops.set_default_gemm_workspace(torch.empty(16 * 2**20, dtype=torch.float32, device=dev))
+ops.set_default_gemm_workspace(torch.empty(int(os.environ.get('WS_M', 16)) * 2**20, dtype=torch.float32, device=dev))
 q = torch.randn(B * N, C, device=dev).half(); k = torch.randn(B * Nk, C, device=dev).half(); v = torch.randn(B * Nk, C, device=dev).half()
 do = torch.randn(B * N, C, device=dev).half()
 o = torch.zeros_like(q); lse = torch.zeros(B, H, N, device=dev); delta = torch.zeros(B, H, N, device=dev)

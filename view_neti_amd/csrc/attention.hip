@@ -346,10 +346,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
 template <int D>
 // min 2 blocks/CU caps the register budget at 256, which makes the compiler keep MFMA accumulators in
 // arch VGPRs (no v_accvgpr copies around the softmax VALU work)
-#ifndef VN_DQ40_BLOCKS
-#define VN_DQ40_BLOCKS 2
-#endif
-__global__ __launch_bounds__(256, (D <= 40 ? VN_DQ40_BLOCKS : D >= 160 ? 1 : 2)) void attn_dq_kernel(AttnArgs a) {
+// (4 blocks per CU for D = 40 was measured: 128 VGPRs + 28 B/lane of scratch, 251-257 us vs 240 us at N = 4096)
+__global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dq_kernel(AttnArgs a) {
   using C = Cfg<D>;
   constexpr int KS_BYTES = 64 * C::ROW;
   constexpr int STAGE = 2 * KS_BYTES + 128;  // K and V tiles (row-major) + slack for the transposed reads' d-padding
