@@ -1,0 +1,45 @@
+"""bench.py's contract (one JSON line; N ranks launched by torch.distributed.run) exercised on ONE GPU: the N > 1 control
+flow — rendezvous on 127.0.0.1, per-rank engine, captured graph A / all-reduce / graph B, barrier + max-over-ranks timing,
+rank 0 prints — runs with the gloo backend standing in for RCCL (VNETI_DIST_BACKEND=gloo; every rank uses cuda:0)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly ONE JSON line expected, got {len(lines)}: {r.stdout[-500:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1200)
+def test_bench_single_gpu_line_tiny():
+    d = _run([sys.executable, "bench.py", "--model", "tiny", "--resolution", "64", "--batch", "2", "--steps", "3",
+              "--warmup", "1", "--no-cpu-baseline"], {})
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "steps/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f16" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["algorithmic_bytes_per_launch"] > 0 and r["avg_launch_us"] > 0
+    assert abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_two_ranks_on_one_gpu():
+    port = 29700 + os.getpid() % 200
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+              "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--model", "tiny", "--resolution", "64",
+              "--batch", "2", "--steps", "3", "--warmup", "1"],
+             {"VNETI_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 2000.0) < 2.0  # whole-job rate: 2 ranks' steps / max time
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
