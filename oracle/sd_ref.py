@@ -433,7 +433,8 @@ def get_velocity(ac: torch.Tensor, x0, noise, t):
 # the train step (Coach.train body, training/coach.py:154-218) for learnable_mode 0
 # ------------------------------------------------------------------------------------------
 def text_conditioning(clip_w: W, clip_cfg, mapper_p: W, w_enc, norm_scale, input_ids, placeholder_object,
-                      timesteps, alpha=0.2, unconstrained=False, n_layers=16, view=None, hidden_masks=None):
+                      timesteps, alpha=0.2, unconstrained=False, n_layers=16, view=None, hidden_masks=None,
+                      output_bypass=True):
     """Coach.get_text_conditioning (training/coach.py:276-311): one text-encoder pass per UNet
     cross-attention layer; returns the XTI context dict.
     view = optional dict(p, w_enc, norm_scale, placeholder, params, alpha, unconstrained, hidden_masks).
@@ -444,21 +445,24 @@ def text_conditioning(clip_w: W, clip_cfg, mapper_p: W, w_enc, norm_scale, input
         layer = torch.full((B,), float(l))
         tm = None if hidden_masks is None else hidden_masks[l]
         if "input_layer.weight" in mapper_p:  # legacy object mapper (arch_view_net <= 14): w_enc is NeTIPositionalEncoding.w
-            word, byp = mapper_forward_legacy(mapper_p, w_enc, timesteps, layer, norm_scale, True, truncation_mask=tm)
+            word, byp = mapper_forward_legacy(mapper_p, w_enc, timesteps, layer, norm_scale, output_bypass,
+                                              truncation_mask=tm)
         else:
-            word, byp = mapper_forward(mapper_p, w_enc, timesteps, layer, norm_scale, True, n_layers, truncation_mask=tm)
+            word, byp = mapper_forward(mapper_p, w_enc, timesteps, layer, norm_scale, output_bypass, n_layers,
+                                       truncation_mask=tm)
         kw = {}
         if view is not None:
             vm = view.get("hidden_masks")
-            wv, bv = mapper_forward(view["p"], view["w_enc"], timesteps, layer, view["norm_scale"], True,
-                                    n_layers, view_params=view["params"],
+            wv, bv = mapper_forward(view["p"], view["w_enc"], timesteps, layer, view["norm_scale"],
+                                    view.get("output_bypass", True), n_layers, view_params=view["params"],
                                     truncation_mask=None if vm is None else vm[l])
             kw = dict(placeholder_view=view["placeholder"], word_view=wv, bypass_view=bv,
                       unconstrained_view=view.get("unconstrained", False), alpha_view=view.get("alpha", alpha))
         last, last_b = neti_text_encoder(clip_w, clip_cfg, input_ids, placeholder_object, word, byp,
                                          unconstrained, alpha, **kw)
         hs[f"CONTEXT_TENSOR_{l}"] = last
-        hs[f"CONTEXT_TENSOR_BYPASS_{l}"] = last_b
+        if last_b is not None:  # no mapper with output_bypass: the key is absent (coach.py:300-304), V reads CONTEXT_TENSOR
+            hs[f"CONTEXT_TENSOR_BYPASS_{l}"] = last_b
     return hs
 
 

@@ -222,3 +222,79 @@ def test_module_call_protocol_text_encoder():
     # the plain input_ids= path (negative prompt, sd_pipeline_call.py:35-39): no bypass variant
     plain, none = enc(input_ids=ids)
     assert none is None and _rel(plain[0], R.clip_plain(wr, cfg, ids)) < 5e-3
+
+
+@pytest.mark.parametrize("with_view,byp_obj,byp_view", [(False, False, True), (True, False, True), (True, True, False),
+                                                        (True, False, False)])
+def test_text_engine_mappers_without_textual_bypass(with_view, byp_obj, byp_view):
+    """`output_bypass_{object,view} = False` (models/neti_mapper.py:79-81,419-424; net_clip_text_embedding.py:88-90): such a
+    mapper emits the word embedding only (output layer D wide); where no mapper emits a bypass the value context is the key
+    context (`CONTEXT_TENSOR_BYPASS_i` absent, xti_attention_processor.py:19-20,39-42)."""
+    from oracle import sd_ref as R
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.text import MapperState, TextEngine, flatten_mapper_state
+    from view_neti_amd.mapper import fourier_frequencies
+    dev = "cuda"
+    cfg = sc.tiny().clip
+    D, L, nl, B = cfg.hidden_size, cfg.max_positions, 16, 2
+    w = synth.clip_weights(cfg)
+    wr = {k: (v.half().float() if (k.endswith("weight") and v.dim() == 2 and "embedding" not in k) else v)
+          for k, v in w.items()}
+    ph_obj, ph_view = cfg.vocab_size - 3, cfg.vocab_size - 4
+    ids = synth.input_ids(B, ph_obj, cfg.vocab_size, L, view_placeholder_id=ph_view if with_view else None)
+    t = torch.tensor([17, 803])
+    gen = torch.Generator().manual_seed(3)
+    rn = lambda *s, sc_=0.1: torch.randn(*s, generator=gen) * sc_
+
+    def rand_mapper(sigmas, bypass):
+        od = 2 * D if bypass else D
+        sd = {"net.0.weight": rn(64, 64, sc_=0.15), "net.0.bias": rn(64), "net.1.weight": 1 + rn(64), "net.1.bias": rn(64),
+              "net.3.weight": rn(64, 64, sc_=0.15), "net.3.bias": rn(64), "net.4.weight": 1 + rn(64), "net.4.bias": rn(64),
+              "output_layer.0.weight": rn(od, 64, sc_=0.15), "output_layer.0.bias": rn(od)}
+        return sd, fourier_frequencies(sigmas, 64, 0, preserve_rng=True)
+
+    sdo, w_o = rand_mapper([0.03, 2.0], byp_obj)
+    ctx_k = torch.zeros(nl, B * L, D, dtype=torch.float16, device=dev)
+    ctx_v = torch.zeros_like(ctx_k)
+    dk = (synth.gaussian((nl, B * L, D), 11) * 0.5).half()
+    dv = (synth.gaussian((nl, B * L, D), 12) * 0.5).half()
+    po = flatten_mapper_state(sdo).to(dev)
+    go = torch.zeros_like(po)
+    mo = MapperState(po, w_o.to(dev), 0.4, 0.2, output_bypass=byp_obj)
+    kw, view = {}, None
+    if with_view:
+        sdv, w_v = rand_mapper([0.03, 2.0] + [0.5] * 12, byp_view)
+        vparams = torch.rand(B, 12, generator=gen) * 2 - 1
+        pv = flatten_mapper_state(sdv).to(dev)
+        gv = torch.zeros_like(pv)
+        kw = dict(mapper_view=MapperState(pv, w_v.to(dev), 0.35, 0.3, output_bypass=byp_view), grads_view=gv)
+    eng = TextEngine(cfg, wr, nl, B, t.to(dev), ctx_k, ctx_v, dk.to(dev), dv.to(dev), mo, go, **kw)
+    eng.set_batch(ids, torch.full((B,), ph_obj), torch.full((B,), ph_view) if with_view else None,
+                  vparams if with_view else None)
+    eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    p_o = {k: v.clone().requires_grad_(True) for k, v in sdo.items()}
+    if with_view:
+        p_v = {k: v.clone().requires_grad_(True) for k, v in sdv.items()}
+        view = dict(p=p_v, w_enc=w_v, norm_scale=0.35, placeholder=torch.full((B,), ph_view), params=vparams, alpha=0.3,
+                    output_bypass=byp_view)
+    hs = R.text_conditioning(wr, cfg, p_o, w_o, 0.4, ids, torch.full((B,), ph_obj), t, alpha=0.2, n_layers=nl, view=view,
+                             output_bypass=byp_obj)
+    any_bypass = byp_obj or (with_view and byp_view)
+    assert ("CONTEXT_TENSOR_BYPASS_0" in hs) == any_bypass
+    rk = torch.stack([hs[f"CONTEXT_TENSOR_{i}"] for i in range(nl)]).reshape(nl, B * L, D)
+    rv = torch.stack([hs.get(f"CONTEXT_TENSOR_BYPASS_{i}", hs[f"CONTEXT_TENSOR_{i}"]) for i in range(nl)]).reshape(nl, B * L, D)
+    ek, ev = _rel(ctx_k, rk.detach()), _rel(ctx_v, rv.detach())
+    assert ek < 5e-3 and ev < 5e-3
+    if not any_bypass:
+        assert torch.equal(ctx_k, ctx_v)
+    ((rk * dk.float()).sum() + (rv * dv.float()).sum()).backward()
+    ref_g = flatten_mapper_state({k: v.grad for k, v in p_o.items()})
+    eg = _rel(go, ref_g)
+    print(f"[text no-bypass view={with_view} obj_bypass={byp_obj} view_bypass={byp_view}] ctx_k {ek:.2e} ctx_v {ev:.2e} "
+          f"object grad rel {eg:.2e} ({ref_g.numel()} params)")
+    assert eg < 3e-2
+    if with_view:
+        ref_gv = flatten_mapper_state({k: v.grad for k, v in p_v.items()})
+        assert _rel(gv, ref_gv) < 3e-2

@@ -95,7 +95,8 @@ class Coach:
         kw = {}
         if self.mapper_view is not None:
             # modes 4/5: the loaded mapper carries the alpha it was trained with (checkpoint_handler.py:163-169, Q8)
-            kw = dict(mapper_view=self.mapper_view.mapper_state(), w_enc_view=self.mapper_view.encoder.w,
+            kw = dict(output_bypass_view=self.mapper_view.output_bypass,
+                      mapper_view=self.mapper_view.mapper_state(), w_enc_view=self.mapper_view.encoder.w,
                       norm_scale_view=self.mapper_view.norm_scale, alpha_view=self.mapper_view.output_bypass_alpha,
                       train_view=cfg.learnable_mode != 5)
         self.engine = TrainStepEngine(
@@ -239,13 +240,17 @@ class Coach:
             raise NotImplementedError("the HIP engine implements arch_view_net = 15 (with arch_view_disable_tl False, "
                                       "neti_mapper.py:481-483) and the legacy object mapper of arch_view_net <= 14")
         if m.original_ti:
-            raise NotImplementedError("original_ti (plain textual inversion baseline) is outside the NeTI hot path")
+            # not "unsupported here" but broken upstream: with original_ti the mapper returns a bare tensor and
+            # NeTICLIPTextEmbeddings.forward reads `.output_bypass_alpha` off it (net_clip_text_embedding.py:80) —
+            # AttributeError in the reference itself (probed with the real modules)
+            raise NotImplementedError("original_ti: the reference's own path raises AttributeError "
+                                      "(net_clip_text_embedding.py:80 on the tensor neti_mapper.py:183-192 returns)")
         if cfg.learnable_mode == 1:
             raise NotImplementedError("learnable_mode 1 (view mapper only, fixed object word) is not built: the engine "
                                       "always trains an object bucket; use mode 2, or mode 5 with a pretrained view mapper")
-        if not (m.output_bypass_object and (m.output_bypass_view or cfg.learnable_mode == 0)):
-            raise NotImplementedError("the HIP text path implements the paper's textual-bypass mappers "
-                                      "(model.output_bypass_object / output_bypass_view = True)")
+        if (m.bypass_unconstrained_object and not m.output_bypass_object) or \
+                (m.bypass_unconstrained_view and not m.output_bypass_view):
+            raise ValueError("bypass_unconstrained needs output_bypass (neti_mapper.py:130-132)")
         if len(UNET_LAYERS) != self.sd.unet.n_cross_layers:
             raise ValueError("UNET_LAYERS does not match the UNet")
         lookup = {}
@@ -289,11 +294,13 @@ class Coach:
         eng, D = self.engine, self.cfg.model.word_embedding_dim
         for tid, k in self.object_slot.items():
             obj = self.mapper_object_lookup[tid]
-            obj.load_state_dict(unflatten_mapper_state(eng.object_params(k).cpu(), obj.enc_dim, obj.hidden, 2 * D,
+            od = 2 * D if obj.output_bypass else D
+            obj.load_state_dict(unflatten_mapper_state(eng.object_params(k).cpu(), obj.enc_dim, obj.hidden, od,
                                                        obj.pe_dim), strict=False)
         if self.mapper_view is not None and eng.view_params_flat().numel() > 0:
-            self.mapper_view.load_state_dict(unflatten_mapper_state(eng.view_params_flat().cpu(), 64, 64, 2 * D),
-                                             strict=False)
+            self.mapper_view.load_state_dict(
+                unflatten_mapper_state(eng.view_params_flat().cpu(), 64, 64, 2 * D if self.mapper_view.output_bypass else D),
+                strict=False)
 
     def save(self, embeds_name: str, mapper_name: str):
         if self.rank != 0:

@@ -85,7 +85,7 @@ def load_inference(exp_dir, mapper_stem: str = "mapper-final", batch: int = 1, h
     if mapper_view is not None:
         kw = dict(mapper_view=mapper_view.mapper_state(), w_enc_view=mapper_view.encoder.w,
                   norm_scale_view=mapper_view.norm_scale, alpha_view=m.output_bypass_alpha_view,
-                  unconstrained_view=m.bypass_unconstrained_view)
+                  unconstrained_view=m.bypass_unconstrained_view, output_bypass_view=mapper_view.output_bypass)
     eng = InferenceEngine(sd, unet_w, dec_w, clip_w, batch, height, width, mo.mapper_state(), mo.encoder.w,
                           mo.norm_scale, m.output_bypass_alpha_object, hidden_object=mo.hidden,
                           unconstrained_object=m.bypass_unconstrained_object, device=device,

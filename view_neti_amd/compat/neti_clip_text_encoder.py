@@ -77,18 +77,17 @@ class HipNeTICLIPTextModel(TextEncoderWeights):
             ts = torch.zeros(B, dtype=torch.int64, device=self.dev)
             ck = torch.zeros((self.nl, B * L, D), dtype=torch.float16, device=self.dev)
             cv = torch.zeros_like(ck)
-            kw_o = mo_mod.engine_encoder_kwargs()
-            mo = MapperState(flatten_mapper_state(mo_mod.mapper_state()).to(self.dev),
-                             None if kw_o else mo_mod.encoder.w.to(self.dev).float().contiguous(), mo_mod.norm_scale,
-                             mo_mod.output_bypass_alpha, hidden=mo_mod.hidden, enc_dim=mo_mod.enc_dim,
-                             unconstrained=mo_mod.bypass_unconstrained,
-                             legacy_w_pe=kw_o["legacy_pe_object"].to(self.dev).float().contiguous() if kw_o else None)
+            w = mo_mod.encoder.w.to(self.dev).float().contiguous()
+            mo = MapperState(flatten_mapper_state(mo_mod.mapper_state()).to(self.dev), None if mo_mod.legacy else w,
+                             mo_mod.norm_scale, mo_mod.output_bypass_alpha, hidden=mo_mod.hidden, enc_dim=mo_mod.enc_dim,
+                             unconstrained=mo_mod.bypass_unconstrained, legacy_w_pe=w if mo_mod.legacy else None,
+                             output_bypass=mo_mod.output_bypass)
             mv = None
             if with_view:
                 v = emb.mapper_view
                 mv = MapperState(flatten_mapper_state(v.mapper_state()).to(self.dev),
                                  v.encoder.w.to(self.dev).float().contiguous(), v.norm_scale, v.output_bypass_alpha,
-                                 unconstrained=v.bypass_unconstrained)
+                                 unconstrained=v.bypass_unconstrained, output_bypass=v.output_bypass)
             eng = TextEngine(self.cfg, self.weights, self.nl, B, ts, ck, cv, None, None, mo, None, mv, None, 12, False,
                              self.dev, need_backward=False)
             eng.training = False
@@ -152,6 +151,9 @@ class HipNeTICLIPTextModel(TextEncoderWeights):
         out = _Output(last, last[ar, eot])
         if plain:
             return out, None
+        obj_mod = emb.mapper_object_lookup[obj_id]
+        if not (obj_mod.output_bypass or (with_view and emb.mapper_view.output_bypass)):
+            return out, None  # no mapper emits a bypass vector (neti_clip_text_encoder.py:207-225)
         last_b = cv[layer]
         return out, _Output(last_b, last_b[ar, eot])
 

@@ -153,9 +153,10 @@ class NeTIMapper(nn.Module):
 
     def engine_encoder_kwargs(self):
         """what TrainStepEngine / InferenceEngine need to know about this (object) mapper's encoder"""
+        kw = dict(output_bypass_object=self.output_bypass)
         if self.legacy:
-            return dict(legacy_pe_object=self.encoder.w, enc_dim_object=self.enc_dim)
-        return {}
+            kw.update(legacy_pe_object=self.encoder.w, enc_dim_object=self.enc_dim)
+        return kw
 
     @property
     def pe_dim(self) -> int:

@@ -48,7 +48,7 @@ class ValidationHandler:
             mv = coach.mapper_view
             frozen = eng.view_params_flat().numel() == 0  # modes 4/5 train no view mapper: it is not in the bucket
             kw = dict(w_enc_view=mv.encoder.w, norm_scale_view=mv.norm_scale, alpha_view=m.output_bypass_alpha_view,
-                      unconstrained_view=m.bypass_unconstrained_view,
+                      unconstrained_view=m.bypass_unconstrained_view, output_bypass_view=mv.output_bypass,
                       **(dict(mapper_view=mv.mapper_state()) if frozen else dict(params_view=eng.view_params_flat())))
         self.slot = torch.zeros(1, dtype=torch.int32, device=eng.dev)
         self.engine = InferenceEngine(

@@ -75,7 +75,7 @@ class InferenceEngine:
                  device: str = "cuda", params_object: Optional[torch.Tensor] = None,
                  params_view: Optional[torch.Tensor] = None, object_slot: Optional[torch.Tensor] = None,
                  object_slot_stride: int = 0, legacy_pe_object: Optional[torch.Tensor] = None,
-                 enc_dim_object: int = 64):
+                 enc_dim_object: int = 64, output_bypass_object: bool = True, output_bypass_view: bool = True):
         """params_object / params_view: flat device buckets to ALIAS instead of copying the state dicts (validation
         during training reads the live parameters); object_slot (+stride) picks one mapper of a multi-object bucket."""
         self.cfg = cfg
@@ -98,12 +98,13 @@ class InferenceEngine:
                          norm_scale_object, alpha_object, hidden=hidden_object, enc_dim=enc_dim_object,
                          unconstrained=unconstrained_object, slot=object_slot, slot_stride=object_slot_stride,
                          legacy_w_pe=(legacy_pe_object.to(device).float().contiguous()
-                                      if legacy_pe_object is not None else None))
+                                      if legacy_pe_object is not None else None),
+                         output_bypass=output_bypass_object)
         mv = None
         if mapper_view is not None or params_view is not None:
             pv = params_view if params_view is not None else flatten_mapper_state(mapper_view).to(device)
             mv = MapperState(pv, w_enc_view.to(device).float().contiguous(), norm_scale_view, alpha_view,
-                             unconstrained=unconstrained_view)
+                             unconstrained=unconstrained_view, output_bypass=output_bypass_view)
         self.text = TextEngine(cfg.clip, clip_w, nl, batch, self.t_text, self.ctx_k, self.ctx_v, None, None, mo, None,
                                mv, None, n_view_params, False, device, need_backward=False)
         self.text.training = False

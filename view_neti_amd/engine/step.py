@@ -49,7 +49,8 @@ class TrainStepEngine:
                  need_backward: bool = True, grad_accum: int = 1, overlap: bool = True,
                  unconstrained_object: bool = False, unconstrained_view: bool = False,
                  nested_dropout_prob: float = 0.0, hidden_object: int = 64,
-                 legacy_pe_object: Optional[torch.Tensor] = None, enc_dim_object: int = 64):
+                 legacy_pe_object: Optional[torch.Tensor] = None, enc_dim_object: int = 64,
+                 output_bypass_object: bool = True, output_bypass_view: bool = True):
         """mapper_object: one mapper state_dict, or a list of them (learnable_mode 3: one object mapper per
         scene, `mapper_object_lookup`, training/coach.py:505-552) — `set_batch(object_index=k)` picks the one
         the batch trains."""
@@ -97,7 +98,8 @@ class TrainStepEngine:
                          nested_dropout_prob=nested_dropout_prob, slot=self.obj_slot if multi else None,
                          slot_stride=self.n_obj if multi else 0,
                          legacy_w_pe=(legacy_pe_object.to(device).float().contiguous()
-                                      if legacy_pe_object is not None else None))
+                                      if legacy_pe_object is not None else None),
+                         output_bypass=output_bypass_object)
         mv, gv = None, None
         if mapper_view is not None:
             if flat_v is not None:
@@ -106,7 +108,8 @@ class TrainStepEngine:
                 pv = flatten_mapper_state(mapper_view).to(device)
             mv = MapperState(pv, w_enc_view.to(device).float().contiguous(), norm_scale_view, alpha_view,
                              unconstrained=unconstrained_view,
-                             nested_dropout_prob=nested_dropout_prob if flat_v is not None else 0.0)
+                             nested_dropout_prob=nested_dropout_prob if flat_v is not None else 0.0,
+                             output_bypass=output_bypass_view)
         # ---- device-resident scalars ----
         self.grad_accum = grad_accum
         # accelerate scales each micro-loss by 1/accum and DDP averages over ranks: fold both into AdamW

@@ -33,7 +33,11 @@ class MapperState:
 
     def __init__(self, params: torch.Tensor, w_enc: Optional[torch.Tensor], norm_scale: Optional[float], alpha: float,
                  hidden: int = 64, enc_dim: int = 64, unconstrained: bool = False, nested_dropout_prob: float = 0.0,
-                 slot: Optional[torch.Tensor] = None, slot_stride: int = 0, legacy_w_pe: Optional[torch.Tensor] = None):
+                 slot: Optional[torch.Tensor] = None, slot_stride: int = 0, legacy_w_pe: Optional[torch.Tensor] = None,
+                 output_bypass: bool = True):
+        # output_bypass False (models/neti_mapper.py:79-81,419-424): the mapper emits the word embedding only — no
+        # CONTEXT_TENSOR_BYPASS, the value context equals the key context
+        self.output_bypass = output_bypass
         self.legacy_w_pe = legacy_w_pe  # device f32 [num_w][2]; None = Fourier path
         self.pe_dim = 2 * legacy_w_pe.shape[0] if legacy_w_pe is not None else 0
         self.params = params            # flat bucket (of `slot_stride`-spaced mappers when slot is given)
@@ -203,7 +207,7 @@ class TextEngine(Schedule):
         return dict(data=self._buf((R, nfeat), torch.float32), word=self._buf((R, D), torch.float32),
                     byp=self._buf((R, D), torch.float32), dbyp=self._buf((R, D), torch.float32, zero=True),
                     save=self._buf((ops.mapper_save_floats(R, m.enc_dim, m.hidden),), torch.float32),
-                    rowg=self._buf((ops.mapper_rowgrad_floats(R, m.hidden, D),), torch.float32))
+                    rowg=self._buf((ops.mapper_rowgrad_floats(R, m.hidden, D, m.output_bypass),), torch.float32))
 
     def _build(self, w):
         cfg = self.cfg
@@ -219,20 +223,20 @@ class TextEngine(Schedule):
         if mo.legacy_w_pe is not None:
             # legacy object mapper (arch_view_net <= 14): NeTIPositionalEncoding of the raw (t, l) -> trainable input_layer
             # (the tail of the bucket) -> the same MLP kernels fed through `enc_in`
-            self.n_std_obj = ops.mapper_num_params(mo.enc_dim, mo.hidden, D)
+            self.n_std_obj = ops.mapper_num_params(mo.enc_dim, mo.hidden, D, mo.output_bypass)
             self.bo["enc"] = self._buf((R, mo.enc_dim), torch.float32)
             self.bo["denc"] = self._buf((R, mo.enc_dim), torch.float32)
             f.append(lambda: ops.mapper_legacy_input_fwd(mo.params[self.n_std_obj:], self.timesteps, mo.legacy_w_pe,
                                                          self.bo["enc"], nl, B, mo.enc_dim, mo.pe_dim, mo.slot,
                                                          mo.slot_stride))
             f.append(lambda: ops.mapper_fwd(mo.params, None, None, self.hidden_mask_obj, mo.norm_scale, self.bo["word"],
-                                            self.bo["byp"], self.bo["save"], R, mo.enc_dim, mo.hidden, D, True, mo.slot,
-                                            mo.slot_stride, enc_in=self.bo["enc"]))
+                                            self.bo["byp"], self.bo["save"], R, mo.enc_dim, mo.hidden, D, mo.output_bypass,
+                                            mo.slot, mo.slot_stride, enc_in=self.bo["enc"]))
         else:
             f.append(partial(ops.mapper_inputs, self.timesteps, None, self.bo["data"], nl, B))
             f.append(lambda: ops.mapper_fwd(mo.params, self.bo["data"], mo.w_enc, self.hidden_mask_obj, mo.norm_scale,
                                             self.bo["word"], self.bo["byp"], self.bo["save"], R, mo.enc_dim, mo.hidden,
-                                            D, True, mo.slot, mo.slot_stride))
+                                            D, mo.output_bypass, mo.slot, mo.slot_stride))
         self.bv = None
         if self.mv is not None:
             mv = self.mv
@@ -240,7 +244,7 @@ class TextEngine(Schedule):
             f.append(partial(ops.mapper_inputs, self.timesteps, self.view_params, self.bv["data"], nl, B))
             f.append(lambda: ops.mapper_fwd(mv.params, self.bv["data"], mv.w_enc, self.hidden_mask_view,
                                             mv.norm_scale, self.bv["word"], self.bv["byp"], self.bv["save"], R,
-                                            mv.enc_dim, mv.hidden, D, True))
+                                            mv.enc_dim, mv.hidden, D, mv.output_bypass))
         x = self._buf((Rt, D), torch.float32)
         f.append(partial(ops.text_embed, self.tok_emb, self.pos_emb, self.ids, self.pos_obj, self.bo["word"],
                          self.pos_view, self.bv["word"] if self.bv else None, x, nl, B, L, D))
@@ -284,8 +288,10 @@ class TextEngine(Schedule):
         self.last = x
         self.fln_g = self._w32(w["text_model.final_layer_norm.weight"])
         self.fln_b = self._w32(w["text_model.final_layer_norm.bias"])
-        f.append(lambda: ops.text_final_fwd(self.last, self.fln_g, self.fln_b, cfg.eps, self.pos_obj, self.bo["byp"],
-                                            self.mo.alpha, self.pos_view, self.bv["byp"] if self.bv else None,
+        byp_o = self.bo["byp"] if self.mo.output_bypass else None   # None: no bypass row for that mapper, ctx_v = ctx_k there
+        byp_v = self.bv["byp"] if (self.bv and self.mv.output_bypass) else None
+        f.append(lambda: ops.text_final_fwd(self.last, self.fln_g, self.fln_b, cfg.eps, self.pos_obj, byp_o,
+                                            self.mo.alpha, self.pos_view, byp_v,
                                             self.mv.alpha if self.mv else 0.0, self.ctx_k, self.ctx_v, nl, B, L, D,
                                             self.mo.unconstrained, bool(self.mv and self.mv.unconstrained),
                                             self.norm_terms))
@@ -298,10 +304,12 @@ class TextEngine(Schedule):
         F = cfg.intermediate_size
         bw = self.bwd
         dx = self._buf((Rt, D), torch.float32)
-        bw.append(lambda: ops.text_final_bwd(self.last, self.fln_g, cfg.eps, self.pos_obj, self.bo["byp"],
-                                             self.mo.alpha, self.bo["dbyp"], self.pos_view,
-                                             self.bv["byp"] if self.bv else None, self.mv.alpha if self.mv else 0.0,
-                                             self.bv["dbyp"] if self.bv else None, self.dctx_k, self.dctx_v, dx, nl, B,
+        byp_o = self.bo["byp"] if self.mo.output_bypass else None
+        byp_v = self.bv["byp"] if (self.bv and self.mv.output_bypass) else None
+        bw.append(lambda: ops.text_final_bwd(self.last, self.fln_g, cfg.eps, self.pos_obj, byp_o,
+                                             self.mo.alpha, self.bo["dbyp"] if byp_o is not None else None, self.pos_view,
+                                             byp_v, self.mv.alpha if self.mv else 0.0,
+                                             self.bv["dbyp"] if byp_v is not None else None, self.dctx_k, self.dctx_v, dx, nl, B,
                                              L, D, self.mo.unconstrained, bool(self.mv and self.mv.unconstrained),
                                              self.norm_terms))
         g16 = self._buf((Rt, D))
@@ -332,9 +340,9 @@ class TextEngine(Schedule):
         self.dx0 = dx
         mo = self.mo
         bw.append(lambda: ops.mapper_bwd(mo.params, self.hidden_mask_obj, mo.norm_scale, self.bo["word"], self.dx0,
-                                         self.rows_obj, D, self.bo["dbyp"], self.bo["save"], self.bo["rowg"], self.go,
-                                         self.accumulate_grads, R, mo.enc_dim, mo.hidden, D, True, mo.slot,
-                                         mo.slot_stride, denc=self.bo.get("denc")))
+                                         self.rows_obj, D, self.bo["dbyp"] if mo.output_bypass else None, self.bo["save"],
+                                         self.bo["rowg"], self.go, self.accumulate_grads, R, mo.enc_dim, mo.hidden, D,
+                                         mo.output_bypass, mo.slot, mo.slot_stride, denc=self.bo.get("denc")))
         if mo.legacy_w_pe is not None:
             bw.append(lambda: ops.mapper_legacy_input_bwd(self.timesteps, mo.legacy_w_pe, self.bo["denc"],
                                                           self.go[self.n_std_obj:], self.accumulate_grads, self.nl, self.B,
@@ -342,5 +350,6 @@ class TextEngine(Schedule):
         if self.train_view:
             mv = self.mv
             bw.append(lambda: ops.mapper_bwd(mv.params, self.hidden_mask_view, mv.norm_scale, self.bv["word"], self.dx0,
-                                             self.rows_view, D, self.bv["dbyp"], self.bv["save"], self.bv["rowg"],
-                                             self.gv, self.accumulate_grads, R, mv.enc_dim, mv.hidden, D, True))
+                                             self.rows_view, D, self.bv["dbyp"] if mv.output_bypass else None,
+                                             self.bv["save"], self.bv["rowg"], self.gv, self.accumulate_grads, R, mv.enc_dim,
+                                             mv.hidden, D, mv.output_bypass))
