@@ -199,6 +199,31 @@ def test_train_then_generate(tmp_path, monkeypatch):
                             generator=torch.Generator().manual_seed(0), output_type="np", return_dict=False)[0]
     assert out2.shape == (1, 384, 512, 3) and np.isfinite(out2).all() and out2.min() >= 0 and out2.max() <= 1
     assert np.abs(a.astype(np.int32) - (out2[0] * 255).round().astype(np.int32)).mean() < 3.0  # same seed, same image
+    # ---- learnable_mode 5 (BASELINE config 5's training side): a NEW object mapper is trained against the view mapper
+    #      learned above, which stays frozen (coach.py:554-592,745-747) and keeps the bypass alpha it was trained with ----
+    view_ckpt = cfg.log.exp_dir / "mapper-final_view.pt"
+    cfg5 = C.parse(C.RunConfig, [
+        "--learnable_mode", "5", "--data.train_data_dir", str(scan), "--data.placeholder_object_token", "<object>",
+        "--data.camera_representation", "dtu-12d", "--data.dtu_subset", "1", "--data.dtu_preprocess_key", "1",
+        "--data.dataloader_num_workers", "0", "--model.word_embedding_dim", "128", "--model.arch_view_net", "15",
+        "--model.arch_view_disable_tl", "False", "--model.arch_mlp_hidden_dims", "64", "--model.use_nested_dropout", "False",
+        "--model.pe_sigma_exp_key", "2", "--model.pretrained_view_mapper", str(view_ckpt), "--model.output_bypass_alpha_view",
+        "0.7", "--optim.max_train_steps", "2", "--optim.train_batch_size", "1", "--optim.gradient_accumulation_steps", "1",
+        "--optim.mixed_precision", "fp16", "--log.save_steps", "100", "--eval.validation_steps", "100",
+        "--log.exp_dir", str(tmp_path / "out"), "--log.exp_name", "m5"])
+    cfg5.log.exp_dir = cfg5.log.exp_dir / cfg5.log.exp_name
+    cfg5.log.logging_dir = cfg5.log.exp_dir / cfg5.log.logging_dir
+    torch.manual_seed(cfg5.seed)
+    coach5 = Coach(cfg5)
+    e5 = coach5.engine
+    assert e5.view_params_flat().numel() == 0, "the frozen view mapper is not in the trainable bucket"
+    assert torch.equal(e5.text.mv.params.cpu(), eng.view_params_flat().cpu()), "pretrained view mapper loaded"
+    # quirk Q8: the loaded mapper carries the (object) alpha of ITS training config (0.2), not this run's 0.7
+    assert abs(e5.text.mv.alpha - 0.2) < 1e-9
+    pv0, po0 = e5.text.mv.params.clone(), e5.params.clone()
+    coach5.train()
+    assert torch.equal(e5.text.mv.params, pv0) and not torch.equal(e5.params, po0) and e5.opt_step.item() == 2
+    assert (cfg5.log.exp_dir / "mapper-final_object.pt").exists()
 
 
 @pytest.mark.parametrize("aug_key,flip", [(7, True), (5, False)])
