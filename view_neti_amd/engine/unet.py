@@ -48,9 +48,12 @@ class UNetEngine(Schedule):
         self.pred = self._buf((B * height * width, 8))[:, : cfg.out_channels]
         self.dpred = self._buf((B * height * width, 8), zero=True)[:, : cfg.out_channels]
         self._pack_time_weights(weights)
+        self._plan_kv()
         self._build(weights)
+        self._kv_fwd_ops()
         if need_backward:
             self._build_backward()
+            self._kv_bwd_ops()
         if autotune:
             self.autotune()
         self.bind_workspace()
@@ -90,6 +93,62 @@ class UNetEngine(Schedule):
         f.append(partial(ops.gemm, self.t_h, self.w_t2, self.t_emb, bias=self.b_t2, act=ops.ACT_SILU, tile_hint=3))
         f.append(partial(ops.gemm, self.t_emb, self.w_temb_all, self.temb_all, bias=self.b_temb_all, tile_hint=3))
 
+    # ------------------------------------------------------------------ XTI key/value projections, batched
+    def _cross_widths(self):
+        """channel width of every cross-attention layer in XTI order (down blocks, mid, up blocks)"""
+        cfg = self.cfg
+        boc, lpb = cfg.block_out_channels, cfg.layers_per_block
+        ws = []
+        for i, a in enumerate(cfg.down_has_attn):
+            ws += [boc[i]] * lpb if a else []
+        ws.append(boc[-1])
+        for i, a in enumerate(reversed(cfg.down_has_attn)):
+            ws += [tuple(reversed(boc))[i]] * (lpb + 1) if a else []
+        assert len(ws) == self.nl
+        return ws
+
+    def _plan_kv(self):
+        """The 2 x 16 to_k / to_v projections of the XTI contexts (and their 32 dgrads) are 77-row GEMMs: launch
+        latency, not work.  Consecutive layers of one width share stacked weight / K / V buffers so that each run is
+        ONE batched launch per operand (SD-1.5: 5 runs => 10 launches forward, 10 backward, instead of 32 + 32)."""
+        B, L, Dc = self.B, self.L, self.cfg.cross_attention_dim
+        ws = self._cross_widths()
+        self.kv_runs, self.kv_slot = [], {}
+        l0 = 0
+        while l0 < len(ws):
+            n = 1
+            while l0 + n < len(ws) and ws[l0 + n] == ws[l0]:
+                n += 1
+            Cc = ws[l0]
+            run = dict(l0=l0, n=n, C=Cc, wk=self._buf((n, Cc, Dc)), wv=self._buf((n, Cc, Dc)),
+                       k=self._buf((n, B * L, Cc)), v=self._buf((n, B * L, Cc)))
+            if self.need_backward:
+                run.update(wkd=self._buf((n, Dc, Cc)), wvd=self._buf((n, Dc, Cc)),
+                           dk=self._buf((n, B * L, Cc)), dv=self._buf((n, B * L, Cc)))
+            for j in range(n):
+                self.kv_slot[l0 + j] = (run, j)
+            self.kv_runs.append(run)
+            l0 += n
+
+    def _kv_fwd_ops(self):
+        B, L, Dc = self.B, self.L, self.cfg.cross_attention_dim
+        for run in self.kv_runs:
+            l0, n, Cc = run["l0"], run["n"], run["C"]
+            for ctx, wgt, out in ((self.ctx_k, run["wk"], run["k"]), (self.ctx_v, run["wv"], run["v"])):
+                # depends on the text side only: prologue launches
+                self.fwd_pre.append(partial(ops.gemm, ctx[l0], wgt[0], out[0], batch=n, strideA=B * L * Dc,
+                                            strideB=Cc * Dc, strideC=B * L * Cc))
+
+    def _kv_bwd_ops(self):
+        """dctx_k[l] = dK_l . Wk_l, dctx_v[l] = dV_l . Wv_l for every layer, after the last transformer backward
+        (nothing in the UNet backward reads them)"""
+        B, L, Dc = self.B, self.L, self.cfg.cross_attention_dim
+        for run in self.kv_runs:
+            l0, n, Cc = run["l0"], run["n"], run["C"]
+            for dsrc, wgt, dctx in ((run["dk"], run["wkd"], self.dctx_k), (run["dv"], run["wvd"], self.dctx_v)):
+                self.bwd.append(partial(ops.gemm, dsrc[0], wgt[0], dctx[l0], batch=n, strideA=B * L * Cc,
+                                        strideB=Dc * Cc, strideC=B * L * Dc))
+
     def _transformer(self, x: T, Cc, heads, name, w, layer_idx, out_view, h, wd, need_dx=True):
         cfg = self.cfg
         B, L, Dc = self.B, self.L, cfg.cross_attention_dim
@@ -120,15 +179,13 @@ class UNetEngine(Schedule):
         # ---- attn2 (XTI cross attention: K from ctx_k[layer], V from ctx_v[layer]) ----
         n2, r["ln2"] = self._ln(h1, t + "norm2", w)
         r["wq2"] = self._w16(w[t + "attn2.to_q.weight"])
-        r["wk2"] = self._w16(w[t + "attn2.to_k.weight"])
-        r["wv2"] = self._w16(w[t + "attn2.to_v.weight"])
+        run, slot = self.kv_slot[layer_idx]
+        assert run["C"] == Cc, (name, layer_idx, Cc, run["C"])
+        run["wk"][slot].copy_(w[t + "attn2.to_k.weight"])
+        run["wv"][slot].copy_(w[t + "attn2.to_v.weight"])
         q2 = self._buf((M, Cc))
-        k2 = self._buf((B * L, Cc))
-        v2 = self._buf((B * L, Cc))
+        k2, v2 = run["k"][slot], run["v"][slot]   # written by the batched prologue launches (_kv_fwd_ops)
         self.fwd.append(partial(ops.gemm, n2, r["wq2"], q2))
-        # K/V of the XTI contexts depend only on the text side: prologue launches (overlappable)
-        self.fwd_pre.append(partial(ops.gemm, self.ctx_k[layer_idx], r["wk2"], k2))
-        self.fwd_pre.append(partial(ops.gemm, self.ctx_v[layer_idx], r["wv2"], v2))
         o2 = self._buf((M, Cc))
         lse2 = self._buf((B, heads, N), torch.float32)
         self.fwd.append(partial(ops.attn_fwd, q2, k2, v2, o2, lse2, B, heads, N, L, D, scale, False))
@@ -156,7 +213,8 @@ class UNetEngine(Schedule):
                  p=p)
         if self.need_backward:
             tr = lambda a: self._w16(a.t())
-            r["wk2d"], r["wv2d"] = tr(w[t + "attn2.to_k.weight"]), tr(w[t + "attn2.to_v.weight"])
+            run["wkd"][slot].copy_(w[t + "attn2.to_k.weight"].t())
+            run["wvd"][slot].copy_(w[t + "attn2.to_v.weight"].t())
             r["w_outd"] = tr(w[name + "proj_out.weight"].reshape(Cc, Cc))
             r["wff2d"], r["wff1d"] = tr(w[t + "ff.net.2.weight"]), tr(wff1_il)
             r["wo2d"] = tr(w[t + "attn2.to_out.0.weight"])
@@ -197,14 +255,12 @@ class UNetEngine(Schedule):
                               r["scale"], False, O=r["o2"]))
         else:
             bw.append(partial(ops.attn_bwd_delta, do2, r["o2"], delta, B, heads, N, D))
-        # per-layer dK/dV: their projections back to the context gradient are off the critical path (nothing in
-        # the UNet backward reads dctx), so they run as a parallel branch and must not share scratch with later layers
-        dk2 = self._buf((B * L, Cc))
-        dv2 = self._buf((B * L, Cc))
+        # per-layer dK/dV land in the run's stacked buffers; their projections back to the context gradients are
+        # batched after the last layer (_kv_bwd_ops)
+        run, slot = self.kv_slot[li]
+        dk2, dv2 = run["dk"][slot], run["dv"][slot]
         bw.append(partial(ops.attn_bwd_dkv, r["q2"], r["k2"], r["v2"], do2, r["lse2"], delta, dk2, dv2, B, heads, N, L,
                           D, r["scale"], False))
-        bw.append(self._side(partial(ops.gemm, dk2, r["wk2d"], self.dctx_k[li])))
-        bw.append(self._side(partial(ops.gemm, dv2, r["wv2d"], self.dctx_v[li])))
         if not r["need_dx"]:
             return
         dn2 = self._tmp("tA", M, Cc)  # do2 is dead after dq
