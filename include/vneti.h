@@ -125,6 +125,15 @@ int vneti_im2col3x3_small(const void* x, int x_is_f32, long long sb, long long s
                           long long sx, void* out, int Bn, int C, int Hi, int Wi, int Ho, int Wo,
                           int stride, int pad_t, int pad_l, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution of an image with C <= 3 channels, straight from the strided f32 / f16 pixels to the
+ * NHWC f16 output rows (AutoencoderKL encoder.conv_in, diffusers vae.py; reached from training/coach.py:165-169): no
+ * im2col matrix.  `w_packed` = [Co][32] f16 with k = tap * C + c and the rows of every 128-channel block permuted as
+ * view_neti_amd.packing.conv_in_direct does; Co % 128 == 0.  `gn_sums` (optional) accumulates the GroupNorm (sum, sum of
+ * squares) of the stored values, layout and meaning as vneti_gemm_desc.gn_sums with gn_hw = H * W. */
+int vneti_conv3x3_in(const void* x, int x_is_f32, long long sb, long long sc, long long sy, long long sx,
+                     const void* w_packed, const float* bias, void* out, long long ldo, int Bn, int C, int H, int W,
+                     int Co, float* gn_sums, int gn_groups, int gn_slots, void* stream);
+
 /* batched 2-D transpose of f16 matrices: out[b][c][r] = in[b][r][c]; columns of `out` in
  * [rows, ld_out) are zero filled (attention kernels read K^T / V^T / Q^T / dO^T tiles). */
 int vneti_transpose_f16(const void* in, long long ld_in, long long stride_in, void* out,

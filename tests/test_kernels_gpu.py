@@ -325,6 +325,32 @@ def test_im2col_small_and_conv_in():
     check("conv_in via im2col", out.view(Bn, H, W, Co), _nhwc(ref), 2e-3)
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,f32,gn", [(3, 128, 32, 48, True, True), (3, 256, 16, 16, False, True),
+                                              (1, 128, 9, 21, True, False), (2, 128, 40, 24, False, False)])
+def test_conv3x3_in_direct(Ci, Co, H, W, f32, gn):
+    """AutoencoderKL encoder.conv_in straight from the (strided) pixels, with the GroupNorm sums of the stored values"""
+    ops = _ops()
+    from view_neti_amd import packing
+    Bn, G, S = 3, 32, 8
+    x = rnd(Bn, Ci + 1, H + 2, W + 3, seed=21, dtype=torch.float32)
+    xd = (x if f32 else x.half()).to(DEV)[:, :Ci, 1:H + 1, 2:W + 2]     # a strided view: channel, row and batch strides
+    w = rnd(Co, Ci, 3, 3, scale=0.3, seed=22)
+    bias = rnd(Co, seed=23, dtype=torch.float32)
+    out = torch.zeros(Bn * H * W, Co + 8, dtype=torch.float16, device=DEV)[:, :Co]
+    sums = torch.zeros(Bn, S, G, 2, dtype=torch.float32, device=DEV) if gn else None
+    ops.conv3x3_in(xd, packing.conv_in_direct(w).to(DEV), bias.to(DEV), out, Bn, Ci, H, W, xd.stride(),
+                   gn_sums=sums, gn_hw=H * W if gn else 0, gn_groups=G if gn else 0, gn_slots=S if gn else 0)
+    torch.cuda.synchronize()
+    xr = x[:, :Ci, 1:H + 1, 2:W + 2]
+    ref = F.conv2d(xr.half().float(), w.float(), bias, padding=1)
+    check(f"conv_in direct C{Ci} Co{Co}", out.reshape(Bn, H, W, Co), _nhwc(ref), 2e-3)
+    if gn:
+        xo = out.float().cpu().reshape(Bn, H * W, G, Co // G)
+        got = sums.cpu().sum(1)
+        check("conv_in gn sums", got[..., 0], xo.sum((1, 3)), 1e-3)
+        check("conv_in gn sumsq", got[..., 1], (xo * xo).sum((1, 3)), 1e-5)
+
+
 # ------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("Cc,HW", [(320, 256), (128, 1024), (2560, 64), (960, 100), (320, 4096), (128, 40000)])
 @pytest.mark.parametrize("silu", [True, False])

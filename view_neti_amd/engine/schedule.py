@@ -262,6 +262,10 @@ class Schedule:
             cpg = Cc // G
             # split-K launches keep the standalone statistics pass (their epilogue runs in the reduce kernel);
             # an un-tuned launch (split_k not pinned) is pinned to 1 here
+            if getattr(f, "func", None) is ops.conv3x3_in:  # the direct conv_in: no split-K, same gn_sums contract
+                if hw % 256 == 0 and cpg % 4 == 0 and 128 % cpg == 0 and kw.get("gn_sums") is None:
+                    todo.append(rec)
+                continue
             if getattr(f, "func", None) is not ops.gemm or kw.get("batch"):
                 continue
             if kw.get("split_k") != 1:  # 0 / unset = the library heuristic: ask what it resolves to
@@ -280,8 +284,10 @@ class Schedule:
             sums = self.gn_sums[i]
             f = self.fwd[rec["prod"]]
             kw = dict(f.keywords)
-            kw.update(gn_sums=sums, gn_hw=rec["hw"], gn_groups=G, gn_slots=S, split_k=1)
-            self.fwd[rec["prod"]] = self._rebound(f, ops.gemm, kw)
+            kw.update(gn_sums=sums, gn_hw=rec["hw"], gn_groups=G, gn_slots=S)
+            if f.func is ops.gemm:
+                kw.update(split_k=1)
+            self.fwd[rec["prod"]] = self._rebound(f, f.func, kw)
             g = rec["gn"]
             self.fwd[rec["idx"]] = partial(ops.groupnorm_fwd_sums, rec["x"], rec["y"], g["gamma"], g["beta"], sums, S,
                                            g["mean"], g["rstd"], B, rec["hw"], rec["C"], G, rec["eps"], rec["silu"])

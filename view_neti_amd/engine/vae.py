@@ -46,13 +46,19 @@ class VAEEncoderEngine(Schedule):
         B, H, W = self.B, self.H, self.W
         boc = cfg.block_out_channels
         M0 = B * H * W
-        col = self._buf((M0, 64))
-        w_in = self._w16(packing.pad_rows(packing.conv3x3_fwd(w["encoder.conv_in.weight"]), 64))
         b_in = self._w32(w["encoder.conv_in.bias"])
         h0 = self._buf((M0, boc[0]))
-        self.fwd.append(partial(ops.im2col3x3_small, self.x_in, col, B, cfg.in_channels, H, W, H, W, 1, 1, 1,
-                                self.x_in.stride()))
-        self.fwd.append(partial(ops.gemm, col, w_in, h0, bias=b_in))
+        if cfg.in_channels <= 3 and boc[0] % 128 == 0:
+            # straight from the pixels: no [pixels][64] im2col matrix for a layer that is pure output bandwidth
+            w_in = self._w16(packing.conv_in_direct(w["encoder.conv_in.weight"]))
+            self.fwd.append(partial(ops.conv3x3_in, self.x_in, w_in, b_in, h0, B, cfg.in_channels, H, W,
+                                    self.x_in.stride()))
+        else:
+            col = self._buf((M0, 64))
+            w_in = self._w16(packing.pad_rows(packing.conv3x3_fwd(w["encoder.conv_in.weight"]), 64))
+            self.fwd.append(partial(ops.im2col3x3_small, self.x_in, col, B, cfg.in_channels, H, W, H, W, 1, 1, 1,
+                                    self.x_in.stride()))
+            self.fwd.append(partial(ops.gemm, col, w_in, h0, bias=b_in))
         hcur = self._produced(T(h0, need_grad=False))
         cin = boc[0]
         h, wd = H, W

@@ -116,6 +116,7 @@ def call(name: str, *args):
 # argtypes for every int-returning entry point (kept in the same order as include/vneti.h)
 SIGNATURES = {
     "im2col3x3_small": [c_vp, c_int, c_ll, c_ll, c_ll, c_ll, c_vp] + [c_int] * 9 + [c_vp],
+    "conv3x3_in": [c_vp, c_int, c_ll, c_ll, c_ll, c_ll, c_vp, c_vp, c_vp, c_ll] + [c_int] * 5 + [c_vp, c_int, c_int, c_vp],
     "transpose_f16": [c_vp, c_ll, c_ll, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
     "transpose_f16_multi": [c_vp, c_int, c_vp],
     "img_resample_coeffs": [c_int, c_int, c_int, c_vp, c_vp, c_vp],

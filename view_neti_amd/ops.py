@@ -98,6 +98,15 @@ def im2col3x3_small(x, out, Bn, Cc, Hi, Wi, Ho, Wo, stride, pad_t, pad_l, stride
             Bn, Cc, Hi, Wi, Ho, Wo, stride, pad_t, pad_l, stream())
 
 
+def conv3x3_in(x, w_packed, bias, out, Bn, Cc, H, W, strides, gn_sums=None, gn_hw=0, gn_groups=0, gn_slots=0):
+    """3x3 / stride 1 / pad 1 conv of a <= 3-channel image straight from the pixels (csrc/conv_in.hip);
+    `w_packed` from packing.conv_in_direct; gn_* as in `gemm` (gn_hw must be H * W)"""
+    sb, sc, sy, sx = strides
+    assert gn_sums is None or gn_hw == H * W
+    _l.call("conv3x3_in", _p(x), 1 if x.dtype == torch.float32 else 0, sb, sc, sy, sx, _p(w_packed), _p(bias), _p(out),
+            _ld(out), Bn, Cc, H, W, w_packed.shape[0], _p(gn_sums), gn_groups, gn_slots, stream())
+
+
 def transpose(inp, out, rows, cols, batch, ld_in, stride_in, ld_out, stride_out):
     _l.call("transpose_f16", _p(inp), ld_in, stride_in, _p(out), ld_out, stride_out, rows, cols, batch, stream())
 

@@ -70,3 +70,19 @@ def geglu_interleave_index(n2: int, device=None) -> torch.Tensor:
 def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
     """weight [2F][in] or bias [2F] -> the interleaved row order"""
     return w[geglu_interleave_index(w.shape[0], w.device)].contiguous()
+
+
+def conv_in_direct(w: torch.Tensor) -> torch.Tensor:
+    """[Co, C <= 3, 3, 3] -> [Co][32] for vneti_conv3x3_in: k = tap * C + c (zeros from 9 * C up); inside every 128-channel
+    block, row j * 16 + 4 * fq + e holds output channel (j // 2) * 32 + fq * 8 + (j % 2) * 4 + e, so that after the swapped
+    16x16x32 MFMA a lane owns 8 consecutive channels of each 32-channel chunk (csrc/conv_in.hip)."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and 9 * ci <= 32 and co % 128 == 0
+    m = torch.zeros(co, 32, dtype=w.dtype)
+    m[:, : 9 * ci] = w.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    j = torch.arange(8).view(8, 1, 1)
+    fq = torch.arange(4).view(1, 4, 1)
+    e = torch.arange(4).view(1, 1, 4)
+    src = ((j // 2) * 32 + fq * 8 + (j % 2) * 4 + e).reshape(128)      # packed row j*16 + 4*fq + e  <-  channel src
+    idx = (torch.arange(co // 128).view(-1, 1) * 128 + src.view(1, 128)).reshape(-1)
+    return m[idx].contiguous()
