@@ -98,9 +98,16 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2>
+// FULL = false compiles the gate / second-output / GEGLU / GroupNorm-sum epilogue extensions out: four launches in five use
+// none of them, and every runtime-switched feature in the epilogue is paid by every launch (1-2 us x 575 launches per step,
+// DESIGN.md section 4) even though the main loops compile to the same instructions.
+template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2, bool FULL = true>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs g) {
   static_assert(NSTG == 2 || (NSTG == 3 && DMA), "the 3-stage ring is LDS-DMA only");
+  const half_t* const e_gate = FULL ? g.gate_src : nullptr;
+  half_t* const e_C2 = FULL ? g.C2 : nullptr;
+  float* const e_gn_sums = FULL ? g.gn_sums : nullptr;
+  const int e_geglu = FULL ? g.geglu : 0;
   constexpr int NWM = BM / WM, NWN = BN / WN;
   constexpr int NT = NWM * NWN * 64;
   constexpr int RSTEP = NT / 8;  // tile rows covered by one pass of all threads
@@ -111,7 +118,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   constexpr int LDS_BYTES = (NSTG * STAGE_BYTES > CS_BYTES) ? NSTG * STAGE_BYTES : CS_BYTES;
   // GroupNorm statistics of the output tile (f16 epilogue only): [GN_IMG images][GN_NG groups][2] floats
   constexpr int GN_IMG = 5, GN_NG = BN / 4 + 2;
-  constexpr int GN_BYTES = F32OUT ? 0 : GN_IMG * GN_NG * 2 * 4;
+  constexpr int GN_BYTES = (F32OUT || !FULL) ? 0 : GN_IMG * GN_NG * 2 * 4;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + GN_BYTES];
 
   const int tid = threadIdx.x;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   }
 
   if constexpr (!F32OUT) {
-    if (g.gn_sums) {
+    if (e_gn_sums) {
       float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
       for (int i = tid; i < GN_IMG * GN_NG * 2; i += NT) gacc[i] = 0.f;
     }
@@ -461,7 +468,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     // GroupNorm statistics of what this tile stores: a thread's chunk touches at most two groups (lo/hi, like
     // csrc/norms.hip); its running sums go to the LDS accumulators whenever the image changes and at the end
     float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
-    const bool gn = g.gn_sums != nullptr;
+    const bool gn = e_gn_sums != nullptr;
     const int gn_img0 = gn ? m0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
     const int gn_c = n0 + (tid % CPR) * 8;
     const int gn_glo = gn ? gn_c / g.gn_cpg : 0;
@@ -518,9 +525,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
         }
-        if (g.geglu == 2) {
+        if (e_geglu == 2) {
           // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]
-          const half_t* pp = g.gate_src + (long long)m * g.ld_gate + 2 * n;
+          const half_t* pp = e_gate + (long long)m * g.ld_gate + 2 * n;
           half_t* dp = Cb + (long long)m * g.ldc + 2 * n;
 #pragma unroll
           for (int c2 = 0; c2 < 2; ++c2) {
@@ -538,17 +545,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
           }
           continue;
         }
-        if (g.gate_src) {
-          half8 pre = *reinterpret_cast<const half8*>(g.gate_src + (long long)m * g.ld_gate + n);
+        if (e_gate) {
+          half8 pre = *reinterpret_cast<const half8*>(e_gate + (long long)m * g.ld_gate + n);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)pre[e], g.gate_act));
         }
         *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
-        if (g.geglu == 1) {
+        if (e_geglu == 1) {
           half4 o2;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o2[e] = (half_t)((float)v[e] * vn_gelu_erf((float)v[4 + e]));
-          *reinterpret_cast<half4*>(g.C2 + (long long)m * g.ldc2 + (n >> 1)) = o2;
+          *reinterpret_cast<half4*>(e_C2 + (long long)m * g.ldc2 + (n >> 1)) = o2;
         }
         if (gn) {
 #pragma unroll
@@ -563,20 +570,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
             }
           }
         }
-        if (g.C2 && g.geglu == 0) {
+        if (e_C2 && e_geglu == 0) {
           half8 o2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o2[e] = (half_t)apply_act((float)v[e], g.act2);
-          *reinterpret_cast<half8*>(g.C2 + (long long)m * g.ldc2 + n) = o2;
+          *reinterpret_cast<half8*>(e_C2 + (long long)m * g.ldc2 + n) = o2;
         }
       } else {
         for (int e = 0; e < 8 && n + e < g.N; ++e) {
           float x = (float)v[e];
           if (radd) x = (float)(half_t)(x + (float)radd[e]);
           if (Rb) x = (float)(half_t)(x + (float)Rb[(long long)m * g.ldr + n + e]);
-          if (g.gate_src) x = (float)(half_t)(x * act_grad((float)g.gate_src[(long long)m * g.ld_gate + n + e], g.gate_act));
+          if (e_gate) x = (float)(half_t)(x * act_grad((float)e_gate[(long long)m * g.ld_gate + n + e], g.gate_act));
           Cb[(long long)m * g.ldc + n + e] = (half_t)x;
-          if (g.C2) g.C2[(long long)m * g.ldc2 + n + e] = (half_t)apply_act((float)(half_t)x, g.act2);
+          if (e_C2) e_C2[(long long)m * g.ldc2 + n + e] = (half_t)apply_act((float)(half_t)x, g.act2);
           if (gn) {
             const float xs = (float)(half_t)x;
             if (e < gn_split) {
@@ -598,7 +605,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
         const float sv = gacc[2 * i], qv = gacc[2 * i + 1];
         if (sv == 0.f && qv == 0.f) continue;
         const int img = gn_img0 + i / GN_NG, grp = gn_g0t + i % GN_NG;
-        float* dst = g.gn_sums + (((long long)img * g.gn_slots + slot) * g.gn_G + grp) * 2;
+        float* dst = e_gn_sums + (((long long)img * g.gn_slots + slot) * g.gn_G + grp) * 2;
         unsafeAtomicAdd(dst, sv);  // hardware global_atomic_add_f32
         unsafeAtomicAdd(dst + 1, qv);
       }
@@ -647,6 +654,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
+// gate / second output / GEGLU / GroupNorm sums: the launches that need the FULL epilogue
+inline bool epilogue_extras(const GemmArgs& g) { return g.gate_src || g.C2 || g.gn_sums || g.geglu; }
+
 template <int BM, int BN, int WM, int WN, bool DMA>
 int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
@@ -654,9 +664,11 @@ int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
   dim3 block((BM / WM) * (BN / WN) * 64);
   if (f32out)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, false>), grid, block, 0, st, g);
+  else if (epilogue_extras(g))
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true>), grid, block, 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false>), grid, block, 0, st, g);
   if (g.ksplit > 1) {
     long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
@@ -672,9 +684,11 @@ int launch_cfg_ring(GemmArgs& g, bool f32out, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
   dim3 block((BM / WM) * (BN / WN) * 64);
   if (f32out)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, false>), grid, block, 0, st, g);
+  else if (epilogue_extras(g))
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, true>), grid, block, 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, false>), grid, block, 0, st, g);
   if (g.ksplit > 1) {
     long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
@@ -687,7 +701,10 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g);
+  if (epilogue_extras(g))
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g);
   if (g.ksplit > 1) {
     long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
