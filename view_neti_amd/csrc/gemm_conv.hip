@@ -98,7 +98,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 #endif
 }
 
-// FULL = false compiles the gate / second-output / GEGLU / GroupNorm-sum epilogue extensions out: four launches in five use
+// FULL = false compiles the activation / row-add / gate / second-output / GEGLU / GroupNorm-sum epilogue features out: most launches use
 // none of them, and every runtime-switched feature in the epilogue is paid by every launch (1-2 us x 575 launches per step,
 // DESIGN.md section 4) even though the main loops compile to the same instructions.
 template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2, bool FULL = true>
@@ -108,6 +108,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   half_t* const e_C2 = FULL ? g.C2 : nullptr;
   float* const e_gn_sums = FULL ? g.gn_sums : nullptr;
   const int e_geglu = FULL ? g.geglu : 0;
+  const int e_act = FULL ? g.act : 0;
+  const half_t* const e_rowadd = FULL ? g.rowadd : nullptr;
   constexpr int NWM = BM / WM, NWN = BN / WN;
   constexpr int NT = NWM * NWN * 64;
   constexpr int RSTEP = NT / 8;  // tile rows covered by one pass of all threads
@@ -421,7 +423,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
         float x = acc[i][j][e] * g.alpha;
         int n = n0 + nl + e;
         if (g.bias != nullptr && n < g.N) x += g.bias[n];
-        v[e] = apply_act(x, g.act);
+        v[e] = apply_act(x, e_act);
       }
       if constexpr (F32OUT) {
         f32x4 o = {v[0], v[1], v[2], v[3]};
@@ -513,7 +515,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       }
       if (!valid) continue;
       half8 v = as_half8(*reinterpret_cast<const u32x4*>(smem + ((size_t)r * CS_LD + c) * 2));
-      const half_t* radd = g.rowadd ? g.rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + n : nullptr;
+      const half_t* radd = e_rowadd ? e_rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + n : nullptr;
       if (n + 8 <= g.N) {
         if (radd) {
           half8 t = *reinterpret_cast<const half8*>(radd);
@@ -654,8 +656,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
-// gate / second output / GEGLU / GroupNorm sums: the launches that need the FULL epilogue
-inline bool epilogue_extras(const GemmArgs& g) { return g.gate_src || g.C2 || g.gn_sums || g.geglu; }
+// activation / row-add / gate / second output / GEGLU / GroupNorm sums: the launches that need the FULL epilogue
+inline bool epilogue_extras(const GemmArgs& g) { return g.gate_src || g.C2 || g.gn_sums || g.geglu || g.act || g.rowadd; }
 
 template <int BM, int BN, int WM, int WN, bool DMA>
 int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
@@ -663,7 +665,9 @@ int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   g.tiles_n = cdiv(g.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
   dim3 block((BM / WM) * (BN / WN) * 64);
-  if (f32out)
+  if (f32out && g.act)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, true>), grid, block, 0, st, g);
+  else if (f32out)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, false>), grid, block, 0, st, g);
   else if (epilogue_extras(g))
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true>), grid, block, 0, st, g);
@@ -683,7 +687,9 @@ int launch_cfg_ring(GemmArgs& g, bool f32out, hipStream_t st) {
   g.tiles_n = cdiv(g.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
   dim3 block((BM / WM) * (BN / WN) * 64);
-  if (f32out)
+  if (f32out && g.act)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, true>), grid, block, 0, st, g);
+  else if (f32out)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, false>), grid, block, 0, st, g);
   else if (epilogue_extras(g))
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, true>), grid, block, 0, st, g);
