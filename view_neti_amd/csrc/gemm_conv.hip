@@ -101,7 +101,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 // FULL = false compiles the activation / row-add / gate / second-output / GEGLU / GroupNorm-sum epilogue features out: most launches use
 // none of them, and every runtime-switched feature in the epilogue is paid by every launch (1-2 us x 575 launches per step,
 // DESIGN.md section 4) even though the main loops compile to the same instructions.
-template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2, bool FULL = true>
+template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2, bool FULL = true, bool CONV = true>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs g) {
   static_assert(NSTG == 2 || (NSTG == 3 && DMA), "the 3-stage ring is LDS-DMA only");
   const half_t* const e_gate = FULL ? g.gate_src : nullptr;
@@ -109,6 +109,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   float* const e_gn_sums = FULL ? g.gn_sums : nullptr;
   const int e_geglu = FULL ? g.geglu : 0;
   const int e_act = FULL ? g.act : 0;
+  const int e_conv = CONV ? g.conv_mode : 0;  // CONV = false: the implicit-im2col address paths are compiled out
   const half_t* const e_rowadd = FULL ? g.rowadd : nullptr;
   constexpr int NWM = BM / WM, NWN = BN / WN;
   constexpr int NT = NWM * NWN * 64;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   for (int i = 0; i < A_IT; ++i) {
     int m = m0 + lrow + RSTEP * i;
     bool ok = m < g.M;
-    if (g.conv_mode == 0) {
+    if (e_conv == 0) {
       a_off[i] = ok ? (int)((long long)m * g.lda * 2) + gchunk * 16 : -1;
       a_py[i] = a_px[i] = a_bh[i] = 0;
     } else {
@@ -171,7 +172,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       int oy = rem / g.Wo;
       int ox = rem - oy * g.Wo;
       a_bh[i] = ok ? b * g.Hi : -1;
-      if (g.conv_mode == 1) {
+      if (e_conv == 1) {
         a_py[i] = oy * g.stride - g.pad_t;
         a_px[i] = ox * g.stride - g.pad_l;
       } else {
@@ -192,15 +193,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 
   // offsets of tile kt for row slot i (VN_OOB => zeros)
   auto a_offset = [&](int i, int k0, int dy, int dx, int tapoff) -> uint32_t {
-    if (g.conv_mode == 0) return a_off[i] < 0 ? VN_OOB : (uint32_t)(a_off[i] + k0 * 2);
+    if (e_conv == 0) return a_off[i] < 0 ? VN_OOB : (uint32_t)(a_off[i] + k0 * 2);
     bool ok = a_bh[i] >= 0;
-    if (g.conv_mode == 1 && !g.ups) {
+    if (e_conv == 1 && !g.ups) {
       int iy = a_py[i] + dy, ix = a_px[i] + dx;
       ok = ok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
       return ok ? (uint32_t)(a_off[i] + tapoff) : VN_OOB;
     }
     int iy, ix;
-    if (g.conv_mode == 1) {  // fused nearest-2x upsample
+    if (e_conv == 1) {  // fused nearest-2x upsample
       iy = a_py[i] + dy;
       ix = a_px[i] + dx;
       ok = ok && (unsigned)iy < (unsigned)(2 * g.Hi) && (unsigned)ix < (unsigned)(2 * g.Wi);
@@ -233,7 +234,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     const int k0 = kt * 64;
     bool recompute = first;
     int dy = 0, dx = 0, tapoff = 0;
-    if (g.conv_mode != 0) {
+    if (e_conv != 0) {
       int tap, ci0;
       if (g.korder) {  // chunk-major: consecutive k-steps are the nine taps of one 64-channel chunk
         const int chunk = kt / 9;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
         dy = tap / 3;
         dx = tap - dy * 3;
         // mode 1 (no upsample): offset relative to the corner pixel; otherwise just channel + chunk
-        tapoff = (g.conv_mode == 1 && !g.ups) ? ((dy * g.Wi + dx) * g.ldx2 + ci0 * 2) : (ci0 * 2 + gchunk * 16);
+        tapoff = (e_conv == 1 && !g.ups) ? ((dy * g.Wi + dx) * g.ldx2 + ci0 * 2) : (ci0 * 2 + gchunk * 16);
       }
     }
     if (recompute) {
@@ -666,13 +667,13 @@ int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
   dim3 block((BM / WM) * (BN / WN) * 64);
   if (f32out && g.act)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, true>), grid, block, 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, true, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, true, false>), grid, block, 0, st, g); }
   else if (f32out)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, false>), grid, block, 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, false, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, false, false>), grid, block, 0, st, g); }
   else if (epilogue_extras(g))
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true>), grid, block, 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true, false>), grid, block, 0, st, g); }
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false>), grid, block, 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false, false>), grid, block, 0, st, g); }
   if (g.ksplit > 1) {
     long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
@@ -688,13 +689,13 @@ int launch_cfg_ring(GemmArgs& g, bool f32out, hipStream_t st) {
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
   dim3 block((BM / WM) * (BN / WN) * 64);
   if (f32out && g.act)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, true>), grid, block, 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, true, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, true, false>), grid, block, 0, st, g); }
   else if (f32out)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, false>), grid, block, 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, false, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, false, false>), grid, block, 0, st, g); }
   else if (epilogue_extras(g))
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, true>), grid, block, 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, true, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, true, false>), grid, block, 0, st, g); }
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, false>), grid, block, 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, false, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, false, false>), grid, block, 0, st, g); }
   if (g.ksplit > 1) {
     long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
@@ -708,9 +709,9 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
   g.tiles_n = cdiv(g.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
   if (epilogue_extras(g))
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true, true>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true, false>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g); }
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g);
+    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false, true>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false, false>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g); }
   if (g.ksplit > 1) {
     long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
