@@ -98,19 +98,20 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 #endif
 }
 
-// FULL = false compiles the activation / row-add / gate / second-output / GEGLU / GroupNorm-sum epilogue features out: most launches use
-// none of them, and every runtime-switched feature in the epilogue is paid by every launch (1-2 us x 575 launches per step,
-// DESIGN.md section 4) even though the main loops compile to the same instructions.
-template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2, bool FULL = true, bool CONV = true>
+// EPI selects how much of the fused epilogue is compiled in: 0 = bias + residual (most launches), 1 = + time-embedding
+// row-add and GroupNorm sums (the resnet convolutions, every VAE conv), 2 = + activation, gate, second output, GEGLU.
+// Every runtime-switched feature in the epilogue is paid by every launch (1-2 us x 575 launches per step, DESIGN.md
+// section 4) even though the main loops compile to the same instructions.  CONV = false drops the implicit-im2col paths.
+template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2, int EPI = 2, bool CONV = true>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs g) {
   static_assert(NSTG == 2 || (NSTG == 3 && DMA), "the 3-stage ring is LDS-DMA only");
-  const half_t* const e_gate = FULL ? g.gate_src : nullptr;
-  half_t* const e_C2 = FULL ? g.C2 : nullptr;
-  float* const e_gn_sums = FULL ? g.gn_sums : nullptr;
-  const int e_geglu = FULL ? g.geglu : 0;
-  const int e_act = FULL ? g.act : 0;
-  const int e_conv = CONV ? g.conv_mode : 0;  // CONV = false: the implicit-im2col address paths are compiled out
-  const half_t* const e_rowadd = FULL ? g.rowadd : nullptr;
+  const half_t* const e_gate = EPI == 2 ? g.gate_src : nullptr;
+  half_t* const e_C2 = EPI == 2 ? g.C2 : nullptr;
+  const int e_geglu = EPI == 2 ? g.geglu : 0;
+  const int e_act = EPI == 2 ? g.act : 0;
+  float* const e_gn_sums = EPI >= 1 ? g.gn_sums : nullptr;
+  const half_t* const e_rowadd = EPI >= 1 ? g.rowadd : nullptr;
+  const int e_conv = CONV ? g.conv_mode : 0;
   constexpr int NWM = BM / WM, NWN = BN / WN;
   constexpr int NT = NWM * NWN * 64;
   constexpr int RSTEP = NT / 8;  // tile rows covered by one pass of all threads
@@ -121,7 +122,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   constexpr int LDS_BYTES = (NSTG * STAGE_BYTES > CS_BYTES) ? NSTG * STAGE_BYTES : CS_BYTES;
   // GroupNorm statistics of the output tile (f16 epilogue only): [GN_IMG images][GN_NG groups][2] floats
   constexpr int GN_IMG = 5, GN_NG = BN / 4 + 2;
-  constexpr int GN_BYTES = (F32OUT || !FULL) ? 0 : GN_IMG * GN_NG * 2 * 4;
+  constexpr int GN_BYTES = (F32OUT || EPI == 0) ? 0 : GN_IMG * GN_NG * 2 * 4;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + GN_BYTES];
 
   const int tid = threadIdx.x;
@@ -657,27 +658,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
-// activation / row-add / gate / second output / GEGLU / GroupNorm sums: the launches that need the FULL epilogue
-inline bool epilogue_extras(const GemmArgs& g) { return g.gate_src || g.C2 || g.gn_sums || g.geglu || g.act || g.rowadd; }
+// which epilogue instantiation (EPI) a launch needs
+inline int epilogue_level(const GemmArgs& g) {
+  if (g.gate_src || g.C2 || g.geglu || g.act) return 2;
+  return (g.gn_sums || g.rowadd) ? 1 : 0;
+}
+
+template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG>
+void launch_variant(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  const dim3 block((BM / WM) * (BN / WN) * 64);
+#define VN_GO(E, C) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, F32OUT, DMA, NSTG, E, C>), grid, block, 0, st, g)
+  if constexpr (F32OUT) {  // f32 outputs (split-K partials aside: the CLIP residual stream) know bias / act / residual only
+    if (g.conv_mode) { if (g.act) VN_GO(2, true); else VN_GO(0, true); }
+    else { if (g.act) VN_GO(2, false); else VN_GO(0, false); }
+  } else {
+    const int epi = epilogue_level(g);
+    if (g.conv_mode) { if (epi == 2) VN_GO(2, true); else if (epi == 1) VN_GO(1, true); else VN_GO(0, true); }
+    else { if (epi == 2) VN_GO(2, false); else if (epi == 1) VN_GO(1, false); else VN_GO(0, false); }
+  }
+#undef VN_GO
+}
+
+inline void launch_reduce(const GemmArgs& g, hipStream_t st) {
+  if (g.ksplit > 1) {
+    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
+  }
+}
 
 template <int BM, int BN, int WM, int WN, bool DMA>
 int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
-  dim3 block((BM / WM) * (BN / WN) * 64);
-  if (f32out && g.act)
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, true, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, true, false>), grid, block, 0, st, g); }
-  else if (f32out)
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, false, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, DMA, 2, false, false>), grid, block, 0, st, g); }
-  else if (epilogue_extras(g))
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true, false>), grid, block, 0, st, g); }
-  else
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false, false>), grid, block, 0, st, g); }
-  if (g.ksplit > 1) {
-    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
-  }
+  if (f32out) launch_variant<BM, BN, WM, WN, true, DMA, 2>(g, grid, st);
+  else launch_variant<BM, BN, WM, WN, false, DMA, 2>(g, grid, st);
+  launch_reduce(g, st);
   return vneti_check_launch("gemm_kernel");
 }
 
@@ -687,19 +703,9 @@ int launch_cfg_ring(GemmArgs& g, bool f32out, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
-  dim3 block((BM / WM) * (BN / WN) * 64);
-  if (f32out && g.act)
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, true, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, true, false>), grid, block, 0, st, g); }
-  else if (f32out)
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, false, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, 3, false, false>), grid, block, 0, st, g); }
-  else if (epilogue_extras(g))
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, true, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, true, false>), grid, block, 0, st, g); }
-  else
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, false, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, 3, false, false>), grid, block, 0, st, g); }
-  if (g.ksplit > 1) {
-    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
-  }
+  if (f32out) launch_variant<BM, BN, WM, WN, true, true, 3>(g, grid, st);
+  else launch_variant<BM, BN, WM, WN, false, true, 3>(g, grid, st);
+  launch_reduce(g, st);
   return vneti_check_launch("gemm_kernel");
 }
 
@@ -708,14 +714,8 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
-  if (epilogue_extras(g))
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true, true>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, true, false>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g); }
-  else
-    { if (g.conv_mode) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false, true>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g); else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, DMA, 2, false, false>), grid, dim3((BM / WM) * (BN / WN) * 64), 0, st, g); }
-  if (g.ksplit > 1) {
-    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
-  }
+  launch_variant<BM, BN, WM, WN, false, DMA, 2>(g, grid, st);
+  launch_reduce(g, st);
   return vneti_check_launch("gemm_kernel");
 }
 
