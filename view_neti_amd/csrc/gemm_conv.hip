@@ -413,6 +413,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   }
   // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ---------
   // (the trailing __syncthreads of the K loop guarantees nobody still reads the stages)
+  // the bias of this lane's 4 * NI16 columns in one batch of buffer loads (out-of-range columns and a null bias read as
+  // zeros): written as per-element conditional loads the compiler serialised eight load -> wait round trips per tile
+  f32x4 bv[NI16];
+  {
+    const __amdgpu_buffer_rsrc_t rsBias = vn_make_rsrc(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
+#pragma unroll
+    for (int j = 0; j < NI16; ++j)
+      bv[j] = __builtin_bit_cast(f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + wn0 + j * 16 + 4 * fq) * 4u));
+  }
 #pragma unroll
   for (int i = 0; i < MI16; ++i) {
 #pragma unroll
@@ -422,9 +431,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float x = acc[i][j][e] * g.alpha;
-        int n = n0 + nl + e;
-        if (g.bias != nullptr && n < g.N) x += g.bias[n];
+        float x = acc[i][j][e] * g.alpha + bv[j][e];
         v[e] = apply_act(x, e_act);
       }
       if constexpr (F32OUT) {
