@@ -533,7 +533,21 @@ __device__ __forceinline__ void ln_store(void* y, long long off, const float v[8
 
 constexpr int LN_MAXC = 4;
 
-template <bool XF32>
+// Both kernels are latency-, not bandwidth-bound (2.6 .. 10 MB per launch, 140 launches per step): every load is issued up
+// front and unconditionally -- a lane whose chunk index is past the row re-reads the last chunk and is masked out of the
+// sums and stores -- and gamma / beta come as two 16-byte loads per chunk.  With per-chunk `if (c < CC)` blocks and
+// scalar gamma loads the compiler emitted 12 serialised load -> s_waitcnt vmcnt(0) round trips in the backward kernel.
+// NC = chunks of 8 per lane that the row length needs (1 for C <= 512 ... 4 for C <= 2048).
+__device__ __forceinline__ void ln_load_f32x8(const float* p, float v[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = a[j];
+    v[4 + j] = b[j];
+  }
+}
+
+template <bool XF32, int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, long long ldx,
                                                      half_t* __restrict__ y, long long ldy,
                                                      const float* __restrict__ gamma,
@@ -543,30 +557,41 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const int CC = C / 8;
-  float v[LN_MAXC][8];
+  float v[NC][8], ga[NC][8], be[NC][8];
+  bool ok[NC];
+  int cc[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    ok[i] = c < CC;
+    cc[i] = ok[i] ? c : CC - 1;
+    ln_load<XF32>(x, (long long)row * ldx + cc[i] * 8, v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    ln_load_f32x8(gamma + cc[i] * 8, ga[i]);
+    ln_load_f32x8(beta + cc[i] * 8, be[i]);
+  }
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    int c = lane + 64 * i;
-    if (c < CC) {
-      ln_load<XF32>(x, (long long)row * ldx + c * 8, v[i]);
+  for (int i = 0; i < NC; ++i) {
+    float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[i][j];
-    }
+    for (int j = 0; j < 8; ++j) t += v[i][j];
+    s += ok[i] ? t : 0.f;
   }
   s = wave_sum(s);
   const float m = s / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    int c = lane + 64 * i;
-    if (c < CC) {
+  for (int i = 0; i < NC; ++i) {
+    float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float d = v[i][j] - m;
-        q += d * d;
-      }
+    for (int j = 0; j < 8; ++j) {
+      const float d = v[i][j] - m;
+      t += d * d;
     }
+    q += ok[i] ? t : 0.f;
   }
   q = wave_sum(q);
   const float rs = rsqrtf(q / (float)C + eps);
@@ -575,18 +600,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     if (rstd) rstd[row] = rs;
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    int c = lane + 64 * i;
-    if (c < CC) {
+  for (int i = 0; i < NC; ++i) {
+    if (ok[i]) {
       float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - m) * rs * gamma[c * 8 + j] + beta[c * 8 + j];
-      ln_store<false>(y, (long long)row * ldy + c * 8, o);
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - m) * rs * ga[i][j] + be[i][j];
+      ln_store<false>(y, (long long)row * ldy + cc[i] * 8, o);
     }
   }
 }
 
-template <bool DYF32, bool XF32, bool DXF32>
+template <bool DYF32, bool XF32, bool DXF32, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long long lddy,
                                                      const void* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma,
@@ -599,42 +623,52 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const int CC = C / 8;
+  float xh[NC][8], dh[NC][8], ac[NC][8];
+  bool ok[NC];
+  int cc[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    ok[i] = c < CC;
+    cc[i] = ok[i] ? c : CC - 1;
+    ln_load<XF32>(x, (long long)row * ldx + cc[i] * 8, xh[i]);
+    ln_load<DYF32>(dy, (long long)row * lddy + cc[i] * 8, dh[i]);
+  }
   const float m = mean[row], rs = rstd[row];
-  float xh[LN_MAXC][8], dh[LN_MAXC][8];
+  if (accum) {  // kernel-uniform; the accumulated gradient is requested together with the rest
+#pragma unroll
+    for (int i = 0; i < NC; ++i) ln_load<DXF32>(accum, (long long)row * ldacc + cc[i] * 8, ac[i]);
+  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    int c = lane + 64 * i;
-    if (c < CC) {
-      float xv[8], dv[8];
-      ln_load<XF32>(x, (long long)row * ldx + c * 8, xv);
-      ln_load<DYF32>(dy, (long long)row * lddy + c * 8, dv);
+  for (int i = 0; i < NC; ++i) {
+    float g8[8];
+    ln_load_f32x8(gamma + cc[i] * 8, g8);
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xh[i][j] = (xv[j] - m) * rs;
-        dh[i][j] = dv[j] * gamma[c * 8 + j];
-        s1 += dh[i][j];
-        s2 += dh[i][j] * xh[i][j];
-      }
+    for (int j = 0; j < 8; ++j) {
+      xh[i][j] = (xh[i][j] - m) * rs;
+      dh[i][j] = dh[i][j] * g8[j];
+      t1 += dh[i][j];
+      t2 += dh[i][j] * xh[i][j];
     }
+    s1 += ok[i] ? t1 : 0.f;
+    s2 += ok[i] ? t2 : 0.f;
   }
   s1 = wave_sum(s1) / (float)C;
   s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    int c = lane + 64 * i;
-    if (c < CC) {
+  for (int i = 0; i < NC; ++i) {
+    if (ok[i]) {
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = rs * (dh[i][j] - s1 - xh[i][j] * s2);
       if (accum) {
-        float a[8];
-        ln_load<DXF32>(accum, (long long)row * ldacc + c * 8, a);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] += a[j];
+        for (int j = 0; j < 8; ++j) o[j] += ac[i][j];
       }
-      ln_store<DXF32>(dx, (long long)row * lddx + c * 8, o);
-      if (dx16) ln_store<false>(dx16, (long long)row * ld16 + c * 8, o);  // f16 copy = next GEMM's operand
+      ln_store<DXF32>(dx, (long long)row * lddx + cc[i] * 8, o);
+      if (dx16) ln_store<false>(dx16, (long long)row * ld16 + cc[i] * 8, o);  // f16 copy = next GEMM's operand
     }
   }
 }
@@ -809,12 +843,26 @@ extern "C" int vneti_layernorm_fwd(const void* x, int x_is_f32, long long ldx, v
   VN_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "layernorm_fwd: ld % 8 != 0");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(rows, 4));
-  if (x_is_f32)
-    hipLaunchKernelGGL((ln_fwd_kernel<true>), grid, dim3(256), 0, st, x, ldx, (half_t*)y, ldy, gamma, beta, mean,
-                       rstd, rows, C, eps);
-  else
-    hipLaunchKernelGGL((ln_fwd_kernel<false>), grid, dim3(256), 0, st, x, ldx, (half_t*)y, ldy, gamma, beta, mean,
-                       rstd, rows, C, eps);
+#define LN_FWD(F, NCH)                                                                                        \
+  hipLaunchKernelGGL((ln_fwd_kernel<F, NCH>), grid, dim3(256), 0, st, x, ldx, (half_t*)y, ldy, gamma, beta, mean, \
+                     rstd, rows, C, eps)
+  const int nc = cdiv(C / 8, 64);
+  if (x_is_f32) {
+    switch (nc) {
+      case 1: LN_FWD(true, 1); break;
+      case 2: LN_FWD(true, 2); break;
+      case 3: LN_FWD(true, 3); break;
+      default: LN_FWD(true, 4); break;
+    }
+  } else {
+    switch (nc) {
+      case 1: LN_FWD(false, 1); break;
+      case 2: LN_FWD(false, 2); break;
+      case 3: LN_FWD(false, 3); break;
+      default: LN_FWD(false, 4); break;
+    }
+  }
+#undef LN_FWD
   return vneti_check_launch("layernorm_fwd");
 }
 
@@ -828,9 +876,17 @@ extern "C" int vneti_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy
   VN_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldacc % 8 == 0, "layernorm_bwd: ld % 8 != 0");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(rows, 4));
-#define LN_BWD(A, B, Cc)                                                                                          \
-  hipLaunchKernelGGL((ln_bwd_kernel<A, B, Cc>), grid, dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx, \
+  const int nc = cdiv(C / 8, 64);
+#define LN_BWD_N(A, B, Cc, NCH)                                                                                         \
+  hipLaunchKernelGGL((ln_bwd_kernel<A, B, Cc, NCH>), grid, dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean, rstd, dx, \
                      lddx, dx_accum, ldacc, (half_t*)dx_f16_copy, ldcopy, rows, C)
+#define LN_BWD(A, B, Cc)                      \
+  switch (nc) {                               \
+    case 1: LN_BWD_N(A, B, Cc, 1); break;     \
+    case 2: LN_BWD_N(A, B, Cc, 2); break;     \
+    case 3: LN_BWD_N(A, B, Cc, 3); break;     \
+    default: LN_BWD_N(A, B, Cc, 4); break;    \
+  }
   int key = (dy_is_f32 ? 4 : 0) | (x_is_f32 ? 2 : 0) | (dx_is_f32 ? 1 : 0);
   switch (key) {
     case 0: LN_BWD(false, false, false); break;
@@ -843,6 +899,7 @@ extern "C" int vneti_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy
     default: LN_BWD(true, true, true); break;
   }
 #undef LN_BWD
+#undef LN_BWD_N
   return vneti_check_launch("layernorm_bwd");
 }
 
