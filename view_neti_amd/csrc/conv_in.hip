@@ -70,16 +70,19 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvInArgs a) {
     // this lane's 8 consecutive k of pixel m: k = tap * C + c
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      // branch-free gather: the address is clamped into the image and the value masked afterwards, so the 32 loads of a
+      // lane are all in flight together (as `if (in range) load` the compiler waited for every one of them in turn)
       const int k = fq * 8 + t;
       const int tap = k / a.C, c = k - tap * a.C;
       const int iy = y + tap / 3 - 1, ix = xx + tap % 3 - 1;
-      float v = 0.f;
-      if (mok && tap < 9 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-        const long long off = (long long)b * a.sb + (long long)c * a.sc + (long long)iy * a.sy + (long long)ix * a.sx;
-        if constexpr (F32IN) v = reinterpret_cast<const float*>(a.x)[off];
-        else v = (float)reinterpret_cast<const half_t*>(a.x)[off];
-      }
-      pfs[g][t] = (half_t)v;
+      const bool in = mok && tap < 9 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const int bs = mok ? b : 0, cs = tap < 9 ? c : 0;
+      const int ys = min(max(iy, 0), a.H - 1), xs = min(max(ix, 0), a.W - 1);
+      const long long off = (long long)bs * a.sb + (long long)cs * a.sc + (long long)ys * a.sy + (long long)xs * a.sx;
+      float v;
+      if constexpr (F32IN) v = reinterpret_cast<const float*>(a.x)[off];
+      else v = (float)reinterpret_cast<const half_t*>(a.x)[off];
+      pfs[g][t] = (half_t)(in ? v : 0.f);
     }
   }
 #pragma unroll
