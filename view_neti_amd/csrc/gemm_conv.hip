@@ -634,17 +634,67 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   const long long row = gid / n4;
   const int m = (int)(row % g.M);
   const int bz = (int)(row / g.M);
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
   const int ne = min(4, g.N - c);
-  for (int z = 0; z < g.ksplit; ++z) {
-    const float* p = g.ws + ((long long)(z * g.batch + bz) * g.M + m) * g.N + c;
-    if (ne == 4 && (g.N & 3) == 0) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(p);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += t[e];
-    } else {
-      for (int e = 0; e < ne; ++e) v[e] += p[e];
+  const long long zstride = (long long)g.batch * g.M * g.N;
+  const float* p0 = g.ws + ((long long)bz * g.M + m) * g.N + c;
+  if ((g.N & 3) == 0 && ((g.ldc | g.ldr | g.ld_rowadd | g.ld_gate | g.ldc2) & 3) == 0) {
+    // vector path (every launch of the step): the epilogue operands are requested first, the partials four at a time --
+    // as a scalar loop this kernel was ksplit + 3 serialised load -> wait round trips long
+    const long long co = (long long)bz * g.strideC + (long long)m * g.ldc + c;
+    const long long ro = (long long)bz * g.strideC + (long long)m * g.ldr + c;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, rf = {0.f, 0.f, 0.f, 0.f};
+    half4 rh = {0, 0, 0, 0}, ra = {0, 0, 0, 0}, gt = {0, 0, 0, 0};
+    if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + c);
+    if (g.resid) {
+      if (g.out_f32) rf = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.resid) + ro);
+      else rh = *reinterpret_cast<const half4*>(reinterpret_cast<const half_t*>(g.resid) + ro);
     }
+    if (g.rowadd) ra = *reinterpret_cast<const half4*>(g.rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + c);
+    if (g.gate_src) gt = *reinterpret_cast<const half4*>(g.gate_src + (long long)m * g.ld_gate + c);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= g.ksplit; z += 4) {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(p0 + (z + 0) * zstride);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(p0 + (z + 1) * zstride);
+      const f32x4 t2 = *reinterpret_cast<const f32x4*>(p0 + (z + 2) * zstride);
+      const f32x4 t3 = *reinterpret_cast<const f32x4*>(p0 + (z + 3) * zstride);
+      v += t0;  // same order as the scalar loop
+      v += t1;
+      v += t2;
+      v += t3;
+    }
+    for (; z < g.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(p0 + z * zstride);
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[e] = v[e] * g.alpha;
+      if (g.bias) x[e] += bv[e];
+      x[e] = apply_act(x[e], g.act);
+    }
+    if (g.out_f32) {
+      f32x4 o = {x[0], x[1], x[2], x[3]};
+      if (g.resid) o += rf;
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + co) = o;
+    } else {
+      half4 o, o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = (float)(half_t)x[e];
+        if (g.rowadd) y = (float)(half_t)(y + (float)ra[e]);
+        if (g.resid) y = (float)(half_t)(y + (float)rh[e]);
+        if (g.gate_src) y = (float)(half_t)(y * act_grad((float)gt[e], g.gate_act));
+        o[e] = (half_t)y;
+        o2[e] = (half_t)apply_act((float)(half_t)y, g.act2);
+      }
+      *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(g.C) + co) = o;
+      if (g.C2) *reinterpret_cast<half4*>(g.C2 + (long long)m * g.ldc2 + c) = o2;
+    }
+    return;
+  }
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < g.ksplit; ++z) {
+    const float* p = p0 + z * zstride;
+    for (int e = 0; e < ne; ++e) v[e] += p[e];
   }
   for (int e = 0; e < ne; ++e) {
     float x = v[e] * g.alpha;
