@@ -133,18 +133,21 @@ def pmc_traffic(tile_name: str):
         return {"traffic": None}
     dims = re.findall(r"\d+", tile_name.split(",ring")[0])
     stages = "3" if ",ring3" in tile_name else "2"
-    pats = ["gemm_kernel<" + ", ".join(dims) + ", false, true, " + stages + ">",
+    # every epilogue / conv instantiation of the tile (template tail: ..., EPI, CONV) counts as the same kernel
+    pats = ["gemm_kernel<" + ", ".join(dims) + ", false, true, " + stages,
             "gemm_kernelILi" + "ELi".join(dims) + "ELb0ELb1ELi" + stages + "E"]
     try:
         ks = json.load(open(files[-1]))["kernels"]
     except (OSError, ValueError, KeyError):
         return {"traffic": None}
-    for name, e in ks.items():
-        if any(p in name for p in pats):
-            return {"traffic": e["hbm_bytes"], "traffic_source": os.path.basename(files[-1]),
-                    "traffic_note": "mean HBM bytes/launch over this kernel's launches in one eager train step "
-                                    "(FETCH_SIZE x2 + WRITE_SIZE)"}
-    return {"traffic": None}
+    hit = [e for name, e in ks.items() if any(p in name for p in pats)]
+    n = sum(e.get("launches", 1) for e in hit)
+    if not hit or n == 0:
+        return {"traffic": None}
+    return {"traffic": sum(e["hbm_bytes"] * e.get("launches", 1) for e in hit) / n,
+            "traffic_source": os.path.basename(files[-1]),
+            "traffic_note": "mean HBM bytes/launch over this tile's launches (all epilogue instantiations) in one eager "
+                            "train step (FETCH_SIZE x2 + WRITE_SIZE)"}
 
 
 def usable_cores(cap: int = 32) -> int:
