@@ -18,6 +18,9 @@ namespace {
 // Pass 1 writes per-slab partial sums; pass 2 (one block per sample) finalises mean/rstd in
 // f64; pass 3 applies.  The backward has the same three-pass shape.
 // ------------------------------------------------------------------------------------------
+#ifndef GN_APPLY_U
+#define GN_APPLY_U 4
+#endif
 struct GNGeom {
   int Bn, HW, C, G, cpg, CC, TX, TY, rps, nslab;
 };
@@ -242,13 +245,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
     if (!BWD) {
       // forward: four rows in flight per thread (a single 16-byte load per trip leaves HBM latency exposed:
       // 3.5 TB/s measured on the VAE's 512x512x128 tensors)
-      for (; r + 3 * g.TY < r1; r += 4 * g.TY) {
-        half8 xv[4];
+      constexpr int U = GN_APPLY_U;
+      for (; r + (U - 1) * g.TY < r1; r += U * g.TY) {
+        half8 xv[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < U; ++u)
           xv[u] = *reinterpret_cast<const half8*>(x + ((long long)b * g.HW + r + u * g.TY) * ldx + ch0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           half8 ov;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
