@@ -32,10 +32,11 @@ def enc(v):
     return v
 
 
-def dec(v, dev):
+def dec(v, dev, extra=0):
+    """`extra` elements of slack behind the view: batched launches address batch * stride past the first operand"""
     if isinstance(v, dict) and v.get("__t__"):
         n = 1 + sum((s - 1) * st for s, st in zip(v["shape"], v["stride"])) if v["shape"] else 1
-        base = torch.empty(max(n, 1), dtype=DT[v["dtype"]], device=dev)
+        base = torch.empty(max(n, 1) + extra, dtype=DT[v["dtype"]], device=dev)
         if base.is_floating_point():
             base.normal_()
         else:
@@ -69,8 +70,10 @@ else:
     specs = json.load(open(a.replay))
     for _ in range(a.reps):
         for s in specs:
-            args = [dec(x, dev) for x in s["args"]]
             kw = dec(s["kw"], dev)
+            nb = max(int(kw.get("batch") or 1), 1) - 1
+            extra = [nb * int(kw.get(k) or 0) for k in ("strideA", "strideB", "strideC")]
+            args = [dec(x, dev, extra[i] if i < 3 else 0) for i, x in enumerate(s["args"])]
             ops.gemm(*args, workspace=ws, **kw)
     torch.cuda.synchronize()
     print(f"replayed {len(specs)} launches x {a.reps}")
