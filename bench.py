@@ -37,7 +37,8 @@ MFMA_PEAK_TFLOPS = 2500.0  # fp16/bf16 dense MFMA peak, /opt/skills/guides/MI355
 TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3: "gemm_kernel<64,64,32,32>",
               4: "gemm_kernel<256,128,64,64>", 5: "gemm_kernel<256,256,64,64>", 6: "gemm_kernel<256,128,64,64,ring3>",
               7: "gemm_kernel<256,128,64,32,ring3>", 8: "gemm_kernel<256,128,64,32>", 9: "gemm_kernel<128,128,64,32>",
-              10: "gemm_kernel<128,128,64,32,ring3>", 11: "gemm_kernel<128,64,64,32,ring3>", 12: "gemm_kernel<64,64,32,32,ring3>"}
+              10: "gemm_kernel<128,128,64,32,ring3>", 11: "gemm_kernel<128,64,64,32,ring3>", 12: "gemm_kernel<64,64,32,32,ring3>",
+              13: "gemm_kernel<128,128,64,32,ring4>", 14: "gemm_kernel<128,64,64,32,ring4>", 15: "gemm_kernel<64,64,32,32,ring4>"}
 # algorithmic FLOPs per sample at 512^2, SD-1.5: VAE 1116.7 + CLIP 16x13.3 + UNet fwd 803.3
 # + UNet dgrad 929.4 + CLIP dgrad 216 GF
 ALGO_GFLOP_PER_SAMPLE_512 = 3278.0
@@ -132,7 +133,7 @@ def pmc_traffic(tile_name: str):
     if not files:
         return {"traffic": None}
     dims = re.findall(r"\d+", tile_name.split(",ring")[0])
-    stages = "3" if ",ring3" in tile_name else "2"
+    stages = "3" if ",ring3" in tile_name else "4" if ",ring4" in tile_name else "2"
     # every epilogue / conv instantiation of the tile (template tail: ..., EPI, CONV) counts as the same kernel
     pats = ["gemm_kernel<" + ", ".join(dims) + ", false, true, " + stages,
             "gemm_kernelILi" + "ELi".join(dims) + "ELb0ELb1ELi" + stages + "E"]

@@ -49,7 +49,7 @@ def check(name, got, ref, tol, elem_k=ELEM_K):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 101, 102, 103, 104, 105])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 101, 102, 103, 104, 105])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (128, 64, 64), (77 * 4, 1280, 768), (1000, 8, 192)])
 def test_gemm_plain(hint, M, N, K):
     ops = _ops()
@@ -203,7 +203,7 @@ def test_gemm_geglu_epilogues(hint, M, C):
                  workspace=torch.empty(2 * M * 2 * F4, dtype=torch.float32, device=DEV))
 
 
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9, 14])
 @pytest.mark.parametrize("Bn,HW,C", [(4, 64, 320), (2, 256, 128), (3, 576, 640), (2, 4096, 32 * 4)])
 def test_gemm_groupnorm_sums_and_fused_apply(hint, Bn, HW, C):
     """GroupNorm statistics accumulated by the GEMM epilogue (rows = Bn images of HW pixels, 32 groups) and the
@@ -249,7 +249,7 @@ def _nhwc(x):
 
 @pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
 @pytest.mark.parametrize("case", ["s1", "s2p1", "s2vae", "ups"])
-@pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 101, 103])
+@pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 13, 15, 101, 103])
 def test_conv3x3_fwd(case, hint, korder):
     """both K orders of the implicit GEMM (vneti_gemm_desc.conv_korder): (tap, channel) and (64-channel chunk, tap,
     channel); two chunks so that the orders really differ"""

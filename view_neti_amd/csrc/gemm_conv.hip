@@ -104,7 +104,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 // section 4) even though the main loops compile to the same instructions.  CONV = false drops the implicit-im2col paths.
 template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2, int EPI = 2, bool CONV = true>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs g) {
-  static_assert(NSTG == 2 || (NSTG == 3 && DMA), "the 3-stage ring is LDS-DMA only");
+  static_assert(NSTG == 2 || ((NSTG == 3 || NSTG == 4) && DMA), "the LDS rings are LDS-DMA only");
   const half_t* const e_gate = EPI == 2 ? g.gate_src : nullptr;
   half_t* const e_C2 = EPI == 2 ? g.C2 : nullptr;
   const int e_geglu = EPI == 2 ? g.geglu : 0;
@@ -362,6 +362,35 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       st = st_next;
     }
     __syncthreads();  // (cheap) the epilogue reuses the ring as its C tile
+  } else if constexpr (NSTG == 4) {
+    // 4-stage ring for the short-K, latency-bound launches of the small tiles (K = 320 .. 1280 is 5 .. 20 k-steps of
+    // ~0.3 us each against ~1.5 us of load latency): three stages in flight instead of two, same cross-barrier
+    // fragment prefetch.  DMA of step kt + 3 goes into the stage step kt - 1 has just left.
+    constexpr int PER = A_IT + B_IT;
+    auto wait_landed = [&](int later) {  // `later` = stages requested after the one that must have landed
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    issue(kt_begin, 0, true);
+    if (kt_begin + 1 < kt_end) issue(kt_begin + 1, 1, false);
+    if (kt_begin + 2 < kt_end) issue(kt_begin + 2, 2, false);
+    wait_landed(kt_end - kt_begin - 1);
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, 0);
+    int st = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int st_next = (st + 1) & 3;
+      if (kt + 3 < kt_end) issue(kt + 3, (st + 3) & 3, false);
+      load_frags(1, st, 1);
+      mma(0);
+      wait_landed(kt_end - kt - 2);  // step kt + 1 must be in LDS; kt + 2 and kt + 3 may still be on their way
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < kt_end) load_frags(0, st_next, 0);
+      mma(1);
+      st = st_next;
+    }
+    __syncthreads();
   } else {
     issue(kt_begin, 0, true);
     store_lds(0);
@@ -754,14 +783,14 @@ int launch_cfg(GemmArgs& g, bool f32out, hipStream_t st) {
   return vneti_check_launch("gemm_kernel");
 }
 
-// 3-stage ring variant (LDS-DMA only)
-template <int BM, int BN, int WM, int WN>
+// 3- / 4-stage ring variants (LDS-DMA only)
+template <int BM, int BN, int WM, int WN, int NSTG = 3>
 int launch_cfg_ring(GemmArgs& g, bool f32out, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit);
-  if (f32out) launch_variant<BM, BN, WM, WN, true, true, 3>(g, grid, st);
-  else launch_variant<BM, BN, WM, WN, false, true, 3>(g, grid, st);
+  if (f32out) launch_variant<BM, BN, WM, WN, true, true, NSTG>(g, grid, st);
+  else launch_variant<BM, BN, WM, WN, false, true, NSTG>(g, grid, st);
   launch_reduce(g, st);
   return vneti_check_launch("gemm_kernel");
 }
@@ -779,8 +808,8 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
 struct TileDims {
   int bm, bn;
 };
-constexpr TileDims kTiles[13] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128}, {256, 256}, {256, 128},
-                                {256, 128}, {256, 128}, {128, 128}, {128, 128}, {128, 64},  {64, 64}};
+constexpr TileDims kTiles[16] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128}, {256, 256}, {256, 128}, {256, 128},
+                                {256, 128}, {128, 128}, {128, 128}, {128, 64},  {64, 64},   {128, 128}, {128, 64},  {64, 64}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -815,7 +844,7 @@ extern "C" int vneti_gemm_select_split(int M, int N, int K, int batch, int tile_
   if (batch <= 0) batch = 1;
   int cfg = tile_hint >= 100 ? tile_hint - 100 : tile_hint;
   if (cfg == 0) cfg = select_tile(M, N, batch);
-  if (cfg < 1 || cfg > 12 || K % 64 != 0) return -1;
+  if (cfg < 1 || cfg > 15 || K % 64 != 0) return -1;
   int ks = select_ksplit(M, N, K, batch, cfg, workspace_bytes / 4);
   const int nk = K / 64;
   if (ks > nk) ks = nk;
@@ -938,7 +967,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     cfg -= 100;
   }
   if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
-  VN_REQUIRE(cfg >= 1 && cfg <= 12, "gemm: unknown tile_hint %d", d->tile_hint);
+  VN_REQUIRE(cfg >= 1 && cfg <= 15, "gemm: unknown tile_hint %d", d->tile_hint);
   if (cfg == 5 && f32) cfg = 4;  // the 256x256 tile's f32 epilogue staging would not fit in LDS
   if ((cfg == 6 || cfg == 7) && !dma) cfg = 4;  // the 3-stage ring exists with LDS-DMA only
   if (cfg >= 10 && !dma) cfg = kTiles[cfg].bm == 128 ? (kTiles[cfg].bn == 128 ? 1 : 2) : 3;
@@ -974,6 +1003,10 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     case 10: return launch_cfg_ring<128, 128, 64, 32>(g, f32, st);
     case 11: return launch_cfg_ring<128, 64, 64, 32>(g, f32, st);
     case 12: return launch_cfg_ring<64, 64, 32, 32>(g, f32, st);
+    // 4-stage rings: three stages in flight for the short-K launches
+    case 13: return launch_cfg_ring<128, 128, 64, 32, 4>(g, f32, st);
+    case 14: return launch_cfg_ring<128, 64, 64, 32, 4>(g, f32, st);
+    case 15: return launch_cfg_ring<64, 64, 32, 32, 4>(g, f32, st);
     default:
       return dma ? launch_cfg_f16<256, 256, 64, 64, true>(g, st) : launch_cfg_f16<256, 256, 64, 64, false>(g, st);
   }
