@@ -517,7 +517,9 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dq_kernel(AttnAr
 template <int D>
 // min 2 blocks/CU caps the register budget at 256, which makes the compiler keep MFMA accumulators in
 // arch VGPRs (no v_accvgpr copies around the softmax VALU work)
-__global__ __launch_bounds__(256, (D <= 40 ? 3 : D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnArgs a) {
+// d = 40: TWO blocks per CU on purpose.  At three (168 VGPRs, 24 B/lane of scratch) the 1024-block grid of the 64x64
+// self-attention takes 1.33 residency rounds; at two (179 VGPRs, no scratch) it is exactly two rounds: 405 -> 358 us.
+__global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnArgs a) {
   using C = Cfg<D>;
   // query tile per barrier interval: 64 rows (two 32-row halves computed back to back with the same
   // registers) where two such blocks still fit a CU's LDS, else 32
