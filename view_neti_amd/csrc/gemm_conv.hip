@@ -12,9 +12,10 @@
 //     (the to_q/to_k/to_v/to_out calls of models/xti_attention_processor.py:30-55)
 //   - their input-gradient (dgrad) passes: same kernel, pre-transposed weights.
 //
-// Structure: a workgroup of 4 or 8 waves, each wave owning a WM x WN sub-tile built from
-// v_mfma_f32_32x32x16_f16; BK = 64; two LDS stages of [rows][64 halfs] with the 16-byte chunks
-// XOR-swizzled (conflict-free ds_read_b128).  Two ways of filling a stage:
+// Structure: a workgroup of 4, 8 or 16 waves, each wave owning a WM x WN sub-tile built from
+// v_mfma_f32_16x16x32_f16; BK = 64; LDS stages of [rows][64 halfs] with the 16-byte chunks
+// XOR-swizzled (conflict-free ds_read_b128): two stages, or a 3- / 4-stage ring (NSTG) whose step barrier sits before
+// the last MFMA group so the next step's first fragments are fetched under it.  Two ways of filling a stage:
 //   DMA  = true : `buffer_load_dwordx4 ... offen lds` (LDS-DMA): no staging VGPRs, no ds_write
 //                 pass; the swizzle is applied to the per-lane *source* chunk because the LDS
 //                 destination of an LDS-DMA is lane-linear.  Out-of-range offsets return zeros,
@@ -24,7 +25,8 @@
 // LDS so HBM stores are full 16-byte rows with bias / time-embedding row-add / residual fused.
 // Split-K (grid.z) writes f32 partials to a caller workspace; a second kernel reduces them and
 // applies the same epilogue — used for the low-resolution layers whose M is too small to fill
-// 256 CUs (M = 256/1024 with K up to 23040).
+// 256 CUs (M = 256/1024 with K up to 23040).  The kernel is instantiated per epilogue feature group (EPI) and with /
+// without the implicit-im2col paths (CONV): code size is a per-launch cost (see the template's comment).
 #include "common.h"
 #include "../../include/vneti.h"
 

@@ -6,7 +6,8 @@ distribution moments [B*h*w, 2*latent] (mean | logvar), channels-last f16; sampl
 and add-noise are fused in one later kernel (ops.sample_add_noise).
 
 Notes
-  * conv_in (3 channels) goes through a 27->64 padded im2col straight from the NCHW f32 pixels.
+  * conv_in (3 channels) is its own kernel, straight from the NCHW f32 pixels (csrc/conv_in.hip; the 27->64 padded
+    im2col + GEMM remains for other channel counts).
   * Downsample2D in the VAE pads (0,1,0,1) and uses padding=0: the implicit-GEMM loader's bounds
     check provides the bottom/right zeros.
   * the single-head d=512 mid-block attention uses batched MFMA GEMMs + a row-softmax kernel
