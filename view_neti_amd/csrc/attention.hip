@@ -876,7 +876,9 @@ extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* K, l
   const int nkb = cdiv(Nk, 128), nqt = cdiv(Nq, 32 * DKV_QH(D));
   long long blocks = (long long)nkb * H * Bn;
   int qsplit = 1;
-  if (ws && !causal && blocks < 256 && nqt >= 8) {
+  // (also at exactly one 4-wave block per CU, the 32x32-latent self-attention: one wave per SIMD is latency-bound,
+  //  64 -> 57 us with the query range split in two, reduce launch included)
+  if (ws && !causal && blocks <= 256 && nqt >= 8) {
     qsplit = (int)(512 / blocks);
     if (qsplit > nqt / 4) qsplit = nqt / 4;
     if (qsplit > 32) qsplit = 32;
