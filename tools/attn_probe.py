@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from view_neti_amd import ops
-B, H, N, D = 4, 8, int(os.environ.get("N", 4096)), int(os.environ.get("D", 40))
+B, H, N, D = int(os.environ.get("B", 4)), int(os.environ.get("H", 8)), int(os.environ.get("N", 4096)), int(os.environ.get("D", 40))
 Nk = int(os.environ.get("NK", N))
 C = H * D
 dev = "cuda"
