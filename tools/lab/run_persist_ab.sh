@@ -6,6 +6,8 @@
 # checks tile 13 bit-for-bit against tile 8 (plain / conv / row-add+residual+act / GroupNorm sums), then sweeps K on one box.
 # r02 (same box): Ci=64/128/256: tile 7 349.7 / 530.0 / 925.5 us, tile 13 420.8 / 615.2 / 1085.7 us
 #   => per tile 9.5 us + 1.37 us per k-step (7) against 13-15 us + 1.4-1.5 us per k-step (13).
+# NOTE: the patch was cut against gemm_conv.hip as of commit 7fdf30c (before the epilogue levels / CONV flag / 4-stage
+# rings); it needs a re-base onto the current kernel before this script runs again.
 set -e
 cd "$(dirname "$0")/../.."
 cp view_neti_amd/csrc/common.h /tmp/common.h
