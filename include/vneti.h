@@ -168,6 +168,17 @@ int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long long ldy, co
 int vneti_groupnorm_fwd_sums(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
                              const float* beta, const float* sums, int slots, float* mean, float* rstd,
                              int Bn, int HW, int C, int G, float eps, int silu, void* stream);
+/* The same forward / backward in TWO launches for tensors beyond the one-block-per-group kernel: the statistics pass adds
+   its slab sums to `sums` ([Bn][slots][G][2] floats, zeroed by the caller before the launch, layout of
+   vneti_gemm_desc.gn_sums) and the apply kernel finishes them itself (no finalize launch).  Small tensors run the
+   one-launch kernel of vneti_groupnorm_fwd / _bwd and leave `sums` alone (`ws` of the backward is only used there). */
+int vneti_groupnorm_fwd_2l(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                           const float* beta, float* sums, int slots, float* mean, float* rstd, int Bn, int HW,
+                           int C, int G, float eps, int silu, void* stream);
+int vneti_groupnorm_bwd_2l(const void* dy, long long lddy, const void* x, long long ldx, const float* gamma,
+                           const float* beta, const float* mean, const float* rstd, void* dx, long long lddx,
+                           const void* dx_accum, long long ldacc, float* sums, int slots, float* ws, int Bn,
+                           int HW, int C, int G, int silu, void* stream);
 /* dx = d(loss)/d(x) given dy = d(loss)/d(y); y = silu?(GN(x)).  If dx_accum != NULL it is
  * added (f16, row stride lddx) — used where two gradient paths meet. */
 int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x, long long ldx,

@@ -384,6 +384,21 @@ def test_groupnorm_fwd_bwd(Cc, HW, silu, three_launch, monkeypatch):
     check(f"gn fwd C{Cc} HW{HW} silu{silu}", y.view(Bn, HW, Cc), yr.detach().permute(0, 2, 1), 2e-3)
     check(f"gn bwd C{Cc} HW{HW} silu{silu}", dx.view(Bn, HW, Cc).float().cpu() - acc.view(Bn, HW, Cc).float().cpu(),
           xr.grad.permute(0, 2, 1), 4e-3)
+    # the two-launch form (statistics into caller-zeroed slot sums, finalize folded into the apply kernel)
+    S = 8
+    y2, dx2 = torch.zeros_like(xd), torch.zeros_like(xd)
+    mean2, rstd2 = torch.zeros_like(mean), torch.zeros_like(mean)
+    fs = torch.zeros(Bn, S, G, 2, dtype=torch.float32, device=DEV)
+    bs = torch.zeros(Bn, S, G, 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm_fwd_2l(xd, y2, gamma.to(DEV), beta.to(DEV), fs, S, mean2, rstd2, Bn, HW, Cc, G, eps, silu)
+    ops.groupnorm_bwd_2l(dy.to(DEV).view(Bn * HW, Cc), xd, gamma.to(DEV), beta.to(DEV), mean2, rstd2, dx2, bs, S, ws, Bn,
+                         HW, Cc, G, silu, accum=acc)
+    torch.cuda.synchronize()
+    check(f"gn 2l fwd C{Cc} HW{HW} silu{silu}", y2.view(Bn, HW, Cc), yr.detach().permute(0, 2, 1), 2e-3)
+    check(f"gn 2l bwd C{Cc} HW{HW} silu{silu}", dx2.view(Bn, HW, Cc).float().cpu() - acc.view(Bn, HW, Cc).float().cpu(),
+          xr.grad.permute(0, 2, 1), 4e-3)
+    check("gn 2l mean", mean2, mean, 1e-5)
+    check("gn 2l rstd", rstd2, rstd, 1e-5)
 
 
 @pytest.mark.parametrize("Cc", [320, 768, 1280])

@@ -32,14 +32,17 @@ __device__ __forceinline__ void gn_thread_coords(const GNGeom& g, int& tx, int& 
   active = ty < g.TY;
 }
 
-template <bool BWD, bool SILU>
+// SLOTS = false: this slab's sums go to part[b][slab][G][2] (reduced by gn_finalize_kernel).
+// SLOTS = true : they are ADDED to part[b][slab % slots][G][2] (caller-zeroed), the layout the GEMM epilogues use for
+//                vneti_gemm_desc.gn_sums, so the apply kernel finishes the statistics itself and the finalize launch goes.
+template <bool BWD, bool SILU, bool SLOTS = false>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GNGeom g, const half_t* __restrict__ x, long long ldx,
                                                        const half_t* __restrict__ dy, long long lddy,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd,
-                                                       float* __restrict__ part) {
+                                                       float* __restrict__ part, int slots = 0) {
   __shared__ float gacc[2 * 64 * 2];  // [G<=64][2]
   const int slab = blockIdx.x, b = blockIdx.y;
   for (int i = threadIdx.x; i < 2 * g.G; i += 256) gacc[i] = 0.f;
@@ -119,8 +122,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNGeom g, const half_t* _
     }
   }
   __syncthreads();
-  float* p = part + ((long long)b * g.nslab + slab) * (2 * g.G);
-  for (int i = threadIdx.x; i < 2 * g.G; i += 256) p[i] = gacc[i];
+  if constexpr (SLOTS) {
+    float* p = part + ((long long)b * slots + slab % slots) * (2 * g.G);
+    for (int i = threadIdx.x; i < 2 * g.G; i += 256) unsafeAtomicAdd(p + i, gacc[i]);
+  } else {
+    float* p = part + ((long long)b * g.nslab + slab) * (2 * g.G);
+    for (int i = threadIdx.x; i < 2 * g.G; i += 256) p[i] = gacc[i];
+  }
 }
 
 // one block per sample: reduce the slab partials (256 threads: 256/G lanes per group, f64 sums).
@@ -181,6 +189,20 @@ __device__ __forceinline__ void gn_stat_from_sums(const GNGeom& g, const float* 
   r = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// backward coefficients (S1 / n, S2 / n) of one (sample, group) from slot sums
+__device__ __forceinline__ void gn_coef_from_sums(const GNGeom& g, const float* sums, int slots, int b, int gi, float& c1,
+                                                  float& c2) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int sl = 0; sl < slots; ++sl) {
+    const float* p = sums + (((long long)b * slots + sl) * g.G + gi) * 2;
+    s0 += (double)p[0];
+    s1 += (double)p[1];
+  }
+  const double n = (double)g.HW * g.cpg;
+  c1 = (float)(s0 / n);
+  c2 = (float)(s1 / n);
+}
+
 template <bool BWD, bool SILU, bool FROM_SUMS = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* __restrict__ x, long long ldx,
                                                        const half_t* __restrict__ dy, long long lddy,
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
       be[j] = beta[ch0 + j];
     }
     float mlo, rlo, mhi, rhi;
-    if constexpr (FROM_SUMS) {
+    if constexpr (FROM_SUMS && !BWD) {
       // the statistics pass ran inside the producing GEMM: finish it here (every thread for its two groups;
       // slab 0 also publishes mean / rstd for the backward)
       gn_stat_from_sums(g, sums, slots, b, g0, eps, mlo, rlo);
@@ -235,7 +257,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
       rhi = rstd[b * g.G + g1];
     }
     float c1lo = 0.f, c2lo = 0.f, c1hi = 0.f, c2hi = 0.f;
-    if (BWD) {
+    if constexpr (BWD && FROM_SUMS) {  // the statistics pass added its slab sums to the slots: finish them here
+      gn_coef_from_sums(g, sums, slots, b, g0, c1lo, c2lo);
+      c1hi = c1lo;
+      c2hi = c2lo;
+      if (g1 != g0) gn_coef_from_sums(g, sums, slots, b, g1, c1hi, c2hi);
+    } else if (BWD) {
       c1lo = c1[b * g.G + g0];
       c2lo = c2[b * g.G + g0];
       c1hi = c1[b * g.G + g1];
@@ -798,6 +825,30 @@ extern "C" int vneti_groupnorm_fwd_sums(const void* x, long long ldx, void* y, l
   return vneti_check_launch("groupnorm_fwd_sums");
 }
 
+// Two launches instead of three for the tensors that are too big for the one-block-per-group kernel: the statistics go
+// straight into caller-zeroed slot sums and the apply kernel finishes them (no finalize launch).  Small tensors take the
+// same one-launch kernel as vneti_groupnorm_fwd / _bwd (sums untouched).
+extern "C" int vneti_groupnorm_fwd_2l(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                                      const float* beta, float* sums, int slots, float* mean, float* rstd, int Bn, int HW,
+                                      int C, int G, float eps, int silu, void* stream) {
+  GNGeom g;
+  VN_REQUIRE(gn_geom(g, Bn, HW, C, G) == 0, "groupnorm: unsupported shape B=%d HW=%d C=%d G=%d", Bn, HW, C, G);
+  VN_REQUIRE(x && y && gamma && beta && mean && rstd && sums && slots > 0, "groupnorm_fwd_2l: null pointer");
+  VN_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "groupnorm_fwd_2l: ld must be a multiple of 8");
+  if (gn_use_small(Bn, HW, C, G, false))
+    return vneti_groupnorm_fwd(x, ldx, y, ldy, gamma, beta, mean, rstd, sums, Bn, HW, C, G, eps, silu, stream);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(g.nslab, Bn);
+  hipLaunchKernelGGL((gn_stats_kernel<false, false, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx,
+                     (const half_t*)nullptr, 0LL, gamma, beta, (const float*)nullptr, (const float*)nullptr, sums, slots);
+  return vneti_groupnorm_fwd_sums(x, ldx, y, ldy, gamma, beta, sums, slots, mean, rstd, Bn, HW, C, G, eps, silu, stream);
+}
+
+extern "C" int vneti_groupnorm_bwd_2l(const void* dy, long long lddy, const void* x, long long ldx, const float* gamma,
+                                      const float* beta, const float* mean, const float* rstd, void* dx, long long lddx,
+                                      const void* dx_accum, long long ldacc, float* sums, int slots, float* ws, int Bn,
+                                      int HW, int C, int G, int silu, void* stream);
+
 extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x, long long ldx,
                                    const float* gamma, const float* beta, const float* mean, const float* rstd,
                                    void* dx, long long lddx, const void* dx_accum, long long ldacc, float* ws,
@@ -837,6 +888,34 @@ extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x
                        (const half_t*)dy, lddy, gamma, beta, mean, rstd, (const float*)c1, (const float*)c2,
                        (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc);
   return vneti_check_launch("groupnorm_bwd");
+}
+
+extern "C" int vneti_groupnorm_bwd_2l(const void* dy, long long lddy, const void* x, long long ldx, const float* gamma,
+                                      const float* beta, const float* mean, const float* rstd, void* dx, long long lddx,
+                                      const void* dx_accum, long long ldacc, float* sums, int slots, float* ws, int Bn,
+                                      int HW, int C, int G, int silu, void* stream) {
+  GNGeom g;
+  VN_REQUIRE(gn_geom(g, Bn, HW, C, G) == 0, "groupnorm: unsupported shape B=%d HW=%d C=%d G=%d", Bn, HW, C, G);
+  VN_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && sums && slots > 0, "groupnorm_bwd_2l: null pointer");
+  VN_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldacc % 8 == 0, "groupnorm_bwd_2l: ld % 8 != 0");
+  if (gn_use_small(Bn, HW, C, G, true))
+    return vneti_groupnorm_bwd(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dx_accum, ldacc, ws, Bn, HW, C, G, silu,
+                               stream);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(g.nslab, Bn);
+#define GN_BWD_2L(S)                                                                                                     \
+  hipLaunchKernelGGL((gn_stats_kernel<true, S, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx, (const half_t*)dy, \
+                     lddy, gamma, beta, mean, rstd, sums, slots);                                                         \
+  hipLaunchKernelGGL((gn_apply_kernel<true, S, true>), grid, dim3(256), 0, st, g, (const half_t*)x, ldx, (const half_t*)dy, \
+                     lddy, gamma, beta, mean, rstd, (const float*)nullptr, (const float*)nullptr, (half_t*)dx, lddx,      \
+                     (const half_t*)dx_accum, ldacc, (const float*)sums, slots, 0.f, (float*)nullptr, (float*)nullptr)
+  if (silu) {
+    GN_BWD_2L(true);
+  } else {
+    GN_BWD_2L(false);
+  }
+#undef GN_BWD_2L
+  return vneti_check_launch("groupnorm_bwd_2l");
 }
 
 extern "C" int vneti_layernorm_fwd(const void* x, int x_is_f32, long long ldx, void* y, long long ldy,

@@ -246,7 +246,27 @@ class Schedule:
         t.producer = len(self.fwd) - 1
         return t
 
+    # ------------------------------------------------------------------ two-launch GroupNorm (no finalize launch)
+    GN2_MAX = 512  # (forward, backward) slot-sum slices of a schedule: 2 per GroupNorm
+
+    def _gn2_slice(self):
+        """[B, GN_SLOTS, G, 2] floats of the schedule's slot-sum arena (zeroed by one launch at the head of `fwd`): the
+        statistics pass of a big GroupNorm adds its slab sums there and the apply kernel finishes them
+        (vneti_groupnorm_fwd_2l / _bwd_2l); small GroupNorms never touch it"""
+        if not hasattr(self, "_gn2_arena"):
+            self._gn2_arena = self._buf((self.GN2_MAX, self.B, self.GN_SLOTS, self.groups, 2), torch.float32, zero=True)
+            self._gn2_used = 0
+        assert self._gn2_used < self.GN2_MAX
+        self._gn2_used += 1
+        return self._gn2_arena[self._gn2_used - 1]
+
     def fuse_gn_stats(self):
+        n = self._fuse_gn_stats()
+        if getattr(self, "_gn2_used", 0):
+            self.fwd.insert(0, self._gn2_arena[:self._gn2_used].zero_)
+        return n
+
+    def _fuse_gn_stats(self):
         """After autotuning: wherever a GroupNorm input comes out of one GEMM that runs without split-K, that GEMM's
         epilogue accumulates the per-(sample, group) sums (vneti_gemm_desc.gn_sums) and the GroupNorm becomes ONE
         launch (vneti_groupnorm_fwd_sums) instead of statistics + finalize + apply: one read of the tensor and two
@@ -305,8 +325,15 @@ class Schedule:
                    mean=self._buf((self.B * self.groups,), torch.float32),
                    rstd=self._buf((self.B * self.groups,), torch.float32), silu=silu, hw=hw)
         y = self._buf((x.rows, Cc))
-        self.fwd.append(partial(ops.groupnorm_fwd, x.v, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"],
-                                self.gn_ws, self.B, hw, Cc, self.groups, eps, silu))
+        import os
+        if os.environ.get("VNETI_GN_3L"):  # A/B aid: the statistics / finalize / apply form
+            self.fwd.append(partial(ops.groupnorm_fwd, x.v, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"],
+                                    self.gn_ws, self.B, hw, Cc, self.groups, eps, silu))
+        else:
+            self.fwd.append(partial(ops.groupnorm_fwd_2l, x.v, y, rec["gamma"], rec["beta"], self._gn2_slice(),
+                                    self.GN_SLOTS, rec["mean"], rec["rstd"], self.B, hw, Cc, self.groups, eps, silu))
+            if self.need_backward:
+                rec["bsums"] = self._gn2_slice()
         if x.producer is not None:
             self._gn_fusable.append(dict(idx=len(self.fwd) - 1, prod=x.producer, gn=rec, x=x.v, y=y, hw=hw, C=Cc,
                                          eps=eps, silu=silu))
@@ -314,9 +341,13 @@ class Schedule:
 
     def _gn_bwd_fn(self, rec, dy):
         x = rec["x"]
-        return lambda out, accum: ops.groupnorm_bwd(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
-                                                    self.gn_ws, self.B, rec["hw"], x.cols, self.groups,
-                                                    rec["silu"], accum=accum)
+        if "bsums" not in rec:
+            return lambda out, accum: ops.groupnorm_bwd(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
+                                                        self.gn_ws, self.B, rec["hw"], x.cols, self.groups,
+                                                        rec["silu"], accum=accum)
+        return lambda out, accum: ops.groupnorm_bwd_2l(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
+                                                       rec["bsums"], self.GN_SLOTS, self.gn_ws, self.B, rec["hw"], x.cols,
+                                                       self.groups, rec["silu"], accum=accum)
 
     def _conv_desc(self, Hi, Wi, Ci, Ho, Wo, stride, pad, ups, ldx, mode=1):
         return dict(mode=mode, Hi=Hi, Wi=Wi, Ci=Ci, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad, pad_l=pad, ups=ups,

@@ -131,6 +131,10 @@ SIGNATURES = {
                            c_f, c_int, c_vp],
     "groupnorm_fwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                       c_f, c_int, c_vp],
+    "groupnorm_fwd_2l": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                         c_f, c_int, c_vp],
+    "groupnorm_bwd_2l": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp, c_int, c_vp,
+                         c_int, c_int, c_int, c_int, c_int, c_vp],
     "groupnorm_bwd": [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp,
                       c_int, c_int, c_int, c_int, c_int, c_vp],
     "layernorm_fwd": [c_vp, c_int, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f, c_vp],

@@ -139,6 +139,19 @@ def groupnorm_fwd_sums(x, y, gamma, beta, sums, slots, mean, rstd, Bn, HW, Cc, G
             Bn, HW, Cc, G, eps, 1 if silu else 0, stream())
 
 
+def groupnorm_fwd_2l(x, y, gamma, beta, sums, slots, mean, rstd, Bn, HW, Cc, G, eps, silu):
+    """GroupNorm forward in two launches (statistics into the caller-zeroed `sums` [Bn, slots, G, 2], apply finishes
+    them); small tensors take the one-launch kernel"""
+    _l.call("groupnorm_fwd_2l", _p(x), _ld(x), _p(y), _ld(y), _p(gamma), _p(beta), _p(sums), slots, _p(mean), _p(rstd),
+            Bn, HW, Cc, G, eps, 1 if silu else 0, stream())
+
+
+def groupnorm_bwd_2l(dy, x, gamma, beta, mean, rstd, dx, sums, slots, ws, Bn, HW, Cc, G, silu, accum=None):
+    _l.call("groupnorm_bwd_2l", _p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(beta), _p(mean), _p(rstd),
+            _p(dx), _ld(dx), _p(accum), _ld(accum) if accum is not None else 0, _p(sums), slots, _p(ws),
+            Bn, HW, Cc, G, 1 if silu else 0, stream())
+
+
 def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, dx, ws, Bn, HW, Cc, G, silu, accum=None):
     _l.call("groupnorm_bwd", _p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(beta), _p(mean), _p(rstd),
             _p(dx), _ld(dx), _p(accum), _ld(accum) if accum is not None else 0, _p(ws),
