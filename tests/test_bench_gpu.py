@@ -43,3 +43,18 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 2000.0) < 2.0  # whole-job rate: 2 ranks' steps / max time
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+@pytest.mark.timeout(1200)
+def test_bench_self_launches_two_ranks():
+    """the driver's own invocation: plain `python bench.py --gpus 2` (no launcher) must spawn the 2 ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VNETI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--model", "tiny", "--resolution", "64", "--batch", "2",
+                        "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["dist_backend"] == "gloo"
+    assert d["config"]["rank0_ms_per_step"] <= d["ms_per_step"] * 1.0001

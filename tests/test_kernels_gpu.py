@@ -352,7 +352,10 @@ def test_conv3x3_in_direct(Ci, Co, H, W, f32, gn):
 
 
 # ------------------------------------------------------------------------------------------ norms
-@pytest.mark.parametrize("Cc,HW", [(320, 256), (128, 1024), (2560, 64), (960, 100), (320, 4096), (128, 40000)])
+# the last twelve complete SURVEY App. B's 14 (C, HW) GroupNorm shapes of the SD-1.5 UNet at 64x64 latents
+@pytest.mark.parametrize("Cc,HW", [(320, 256), (128, 1024), (2560, 64), (960, 100), (320, 4096), (128, 40000),
+                                   (640, 4096), (960, 4096), (320, 1024), (640, 1024), (960, 1024), (1280, 1024),
+                                   (1920, 1024), (640, 256), (1280, 256), (1920, 256), (2560, 256), (1280, 64)])
 @pytest.mark.parametrize("silu", [True, False])
 @pytest.mark.parametrize("three_launch", [False, True])
 def test_groupnorm_fwd_bwd(Cc, HW, silu, three_launch, monkeypatch):
@@ -464,12 +467,16 @@ def _attn_ref(q, k, v, H, D, scale, causal):
     (40, 8, 200, 200, False), (40, 2, 300, 77, False), (64, 12, 77, 77, True), (80, 8, 128, 77, False),
     (160, 8, 256, 256, False), (160, 2, 64, 77, False), (64, 3, 200, 200, True), (80, 2, 520, 520, False),
     (40, 8, 1024, 77, False), (80, 4, 515, 77, False),
+    # the step's own shapes (one sample): the dominant 64x64-latent self- and cross-attention, the
+    # 32x32 and 16x16 levels
+    (40, 8, 4096, 4096, False), (40, 8, 4096, 77, False), (80, 8, 1024, 1024, False), (80, 8, 1024, 77, False),
+    (160, 8, 256, 77, False), (160, 8, 64, 64, False),
 ])
 def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
     ops = _ops()
     if ops._default_ws is None:  # enables the q-split dK/dV path for short key sides (cross-attention)
         ops.set_default_gemm_workspace(torch.empty(16 * 2 ** 20, dtype=torch.float32, device=DEV))
-    Bn = 2
+    Bn = 1 if Nq >= 4096 else 2
     Cc = H * D
     scale = D ** -0.5
     q = rnd(Bn, Nq, Cc, seed=31)
@@ -509,6 +516,31 @@ def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
     check(f"attn dq {tag}", dq.view(Bn, Nq, Cc), qr.grad, 6e-3)
     check(f"attn dk {tag}", dk.view(Bn, Nk, Cc), kr.grad, 6e-3)
     check(f"attn dv {tag}", dv.view(Bn, Nk, Cc), vr.grad, 6e-3)
+
+
+def test_vae_single_head_attention_d512():
+    """the VAE mid block's attention (one head of dim C = 512 over N = h*w tokens) as the engine issues it: batched
+    q.k^T GEMM with alpha = C^-1/2 into an [N, ld] score matrix, softmax_rows in place, v transposed, P.v GEMM — vs
+    torch (diffusers 0.14 AttentionBlock; engine/vae.py::_mid_attention)."""
+    ops = _ops()
+    Bn, N, Cc = 2, 1024, 512  # N = 4096 at 512^2 in the step; 1024 keeps the CPU reference quick, same code path
+    ldn = (N + 63) // 64 * 64
+    qkv = rnd(Bn * N, 3 * Cc, seed=51, scale=0.7)
+    q, k, v = (qkv[:, i * Cc:(i + 1) * Cc].float().view(Bn, N, Cc) for i in range(3))
+    ref = torch.softmax(q @ k.transpose(1, 2) * Cc ** -0.5, -1) @ v
+    d = qkv.to(DEV)
+    qd, kd, vd = d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:]
+    scores = torch.zeros(Bn, N, ldn, dtype=torch.float16, device=DEV)
+    ops.gemm(qd, kd, scores, alpha=Cc ** -0.5, batch=Bn, strideA=N * 3 * Cc, strideB=N * 3 * Cc, strideC=N * ldn, M=N, N=N,
+             K=Cc, lda=3 * Cc, ldc=ldn)
+    ops.softmax_rows(scores.view(Bn * N, ldn), Bn * N, N)
+    vt = torch.zeros(Bn, Cc, ldn, dtype=torch.float16, device=DEV)
+    ops.transpose(vd, vt, N, Cc, Bn, 3 * Cc, N * 3 * Cc, ldn, Cc * ldn)
+    o = torch.zeros(Bn * N, Cc, dtype=torch.float16, device=DEV)
+    ops.gemm(scores, vt, o, batch=Bn, strideA=N * ldn, strideB=Cc * ldn, strideC=N * Cc, M=N, N=Cc, K=ldn, lda=ldn, ldc=Cc)
+    torch.cuda.synchronize()
+    check("vae attention d512 probabilities", scores[:, :, :N], torch.softmax(q @ k.transpose(1, 2) * Cc ** -0.5, -1), 3e-3)
+    check("vae attention d512 output", o.view(Bn, N, Cc), ref, 3e-3)
 
 
 def test_transpose_multi():

@@ -371,3 +371,23 @@ def test_legacy_mapper_module_matches_reference_and_round_trips(tmp_path):
     with torch.no_grad():
         w2, b2 = m2(t, lay)
     assert torch.equal(w2, w) and torch.equal(b2, b)
+
+
+def test_bench_gpus_n_self_launches_to_the_ranks():
+    """`python bench.py --gpus 2` (the driver's invocation, no launcher, no WORLD_SIZE) must start 2 ranks through
+    torch.distributed.run on 127.0.0.1; in the GPU-less container each rank then fails at device selection — i.e. it got
+    past the rendezvous-less launch instead of exiting with "launch with torch.distributed.run"."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("covered by tests/test_bench_gpu.py::test_bench_self_launches_two_ranks on a GPU box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--model", "tiny", "--steps", "1", "--warmup", "0"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "launch with torch.distributed.run" not in r.stderr
+    assert r.stderr.count("No HIP GPUs are available") >= 2, r.stderr[-1500:]
+    assert "local_rank" in r.stderr  # torch.distributed.run's failure report: the ranks existed

@@ -219,6 +219,19 @@ def test_module_call_protocol_text_encoder():
         print(f"[module-call protocol layer {layer}] last_hidden_state rel {e0:.2e}, with bypass rel {e1:.2e}")
         assert out[0].shape == (B, L, D) and e0 < 5e-3 and e1 < 5e-3
         assert torch.equal(out.last_hidden_state, out[0]) and out.pooler_output.shape == (B, D)
+    # an in-place update of the mapper (optimizer step, load_state_dict) must be seen: the adapter may neither serve its
+    # cached result nor run the engine on its stale copy of the parameters
+    with torch.no_grad():
+        for prm in mapper.parameters():
+            prm.add_(0.3 * torch.randn(prm.shape))
+    sd2 = {k: v.detach() for k, v in mapper.mapper_state().items()}
+    out2, out2_b = enc(batch=batch)
+    word2, byp2 = R.mapper_forward(sd2, mapper.encoder.w, t, torch.full((B,), float(layer)), 0.4)
+    ref2, ref2_b = R.neti_text_encoder(wr, cfg, ids, torch.full((B,), ph), word2, byp2, False, 0.2)
+    moved = _rel(ref2, ref)
+    print(f"[module-call protocol] after an in-place mapper update: oracle moved by {moved:.2e}, adapter vs new oracle "
+          f"{_rel(out2[0], ref2):.2e} / {_rel(out2_b[0], ref2_b):.2e}")
+    assert moved > 2e-2 and _rel(out2[0], ref2) < 5e-3 and _rel(out2_b[0], ref2_b) < 5e-3
     # the plain input_ids= path (negative prompt, sd_pipeline_call.py:35-39): no bypass variant
     plain, none = enc(input_ids=ids)
     assert none is None and _rel(plain[0], R.clip_plain(wr, cfg, ids)) < 5e-3

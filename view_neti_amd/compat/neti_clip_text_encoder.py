@@ -92,8 +92,25 @@ class HipNeTICLIPTextModel(TextEncoderWeights):
                              self.dev, need_backward=False)
             eng.training = False
             eng.ensure_masks()
-            self._engines[key] = (eng, ts, ck, cv)
-        return self._engines[key]
+            self._engines[key] = (eng, ts, ck, cv, mo, mv)
+        eng, ts, ck, cv, mo, mv = self._engines[key]
+        # the engine computes from its OWN copy of the mapper parameters: refresh it on every (uncached) forward so an
+        # optimizer step / load_state_dict on the modules is seen (108 k floats per mapper)
+        emb = self.text_model.embeddings
+        mo.params.copy_(flatten_mapper_state(emb.mapper_object_lookup[obj_id].mapper_state()))
+        if mv is not None:
+            mv.params.copy_(flatten_mapper_state(emb.mapper_view.mapper_state()))
+        return eng, ts, ck, cv
+
+    def _state_versions(self):
+        """in-place edit counters of everything a forward depends on: every mapper tensor (object AND view) and the
+        token / position tables (the Coach writes the placeholder rows in place, coach.py:367-395)"""
+        emb = self.text_model.embeddings
+        mods = list(emb.mapper_object_lookup.values()) + ([emb.mapper_view] if emb.mapper_view is not None else [])
+        maps = tuple((id(t), int(t._version)) for m in mods for t in m.mapper_state().values())
+        tabs = tuple((id(self.weights[k]), int(self.weights[k]._version))
+                     for k in (TextEncoderWeights.KEY, "text_model.embeddings.position_embedding.weight"))
+        return maps, tabs
 
     @torch.no_grad()
     def __call__(self, input_ids: Optional[torch.Tensor] = None, batch: Optional[NeTIBatch] = None,
@@ -129,9 +146,13 @@ class HipNeTICLIPTextModel(TextEncoderWeights):
             raise ValueError("unet_layers of one call hold one layer index (coach.py:289-295)")
         layer = int(layers[0])
         ts_host = batch.timesteps.cpu().to(torch.int64)
+        maps, tabs = self._state_versions()
+        if tabs != getattr(self, "_table_versions", tabs):
+            self._engines.clear()  # the engines hold f16 device copies of the embedding tables
+        self._table_versions = tabs
         key = (ids.numpy().tobytes(), ph_o.numpy().tobytes(), ph_v.numpy().tobytes(), ts_host.numpy().tobytes(),
                batch.truncation_idx, with_view, None if view_params is None else view_params.cpu().numpy().tobytes(),
-               tuple(int(m.mapper_state()["output_layer.0.bias"]._version) for m in emb.mapper_object_lookup.values()))
+               maps, tabs)
         if key != self._cache_key:
             eng, ts, ck, cv = self._engine(B, obj_id, with_view)
             if with_view and view_params is None:

@@ -758,10 +758,19 @@ extern "C" int vneti_mapper_legacy_input_bwd(const void* timesteps_i64, const fl
   VN_REQUIRE(enc_dim > 0 && enc_dim <= 256 && pe_dim > 0 && pe_dim % 2 == 0 && nl * Bn <= 128,
              "mapper_legacy_input_bwd: unsupported dims E=%d P=%d R=%d", enc_dim, pe_dim, nl * Bn);
   const size_t lds = (size_t)nl * Bn * 256 * sizeof(float);
-  static bool lds_opt_in = false;  // > 64 KiB of dynamic LDS needs the attribute (set once, outside any capture: the
-  if (!lds_opt_in) {               //   first call of an engine is an eager warm-up launch)
-    hipFuncSetAttribute((const void*)legacy_input_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4);
-    lds_opt_in = true;
+  // > 64 KiB of dynamic LDS needs the function attribute — per DEVICE (one process may drive several), and only when
+  // the launch really needs it (nl * Bn > 64 rows); checked, so a part with 64 KiB per workgroup fails here, loudly
+  if (lds > 64 * 1024) {
+    static bool lds_opt_in[64] = {};
+    int dev = 0;
+    VN_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "mapper_legacy_input_bwd: hipGetDevice failed");
+    if (!lds_opt_in[dev]) {
+      hipError_t e = hipFuncSetAttribute((const void*)legacy_input_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         128 * 256 * 4);
+      VN_REQUIRE(e == hipSuccess, "mapper_legacy_input_bwd: %d rows need %zu bytes of LDS: %s", nl * Bn, lds,
+                 hipGetErrorString(e));
+      lds_opt_in[dev] = true;
+    }
   }
   hipLaunchKernelGGL(legacy_input_bwd_kernel, dim3(cdiv(pe_dim, 256)), dim3(256), lds, ST, (const long long*)timesteps_i64,
                      w_pe, denc, grads_in, slot, slot_stride, accumulate, nl, Bn, enc_dim, pe_dim);

@@ -260,8 +260,10 @@ class Schedule:
         self._gn2_used += 1
         return self._gn2_arena[self._gn2_used - 1]
 
-    def fuse_gn_stats(self):
-        n = self._fuse_gn_stats()
+    def fuse_gn_stats(self, fuse: bool = True):
+        """finalises the schedule's GroupNorms; must run once per schedule even with fuse=False: the two-launch
+        GroupNorms add into the slot-sum arena, which has to be cleared at the head of every forward"""
+        n = self._fuse_gn_stats() if fuse else 0
         if getattr(self, "_gn2_used", 0):
             self.fwd.insert(0, self._gn2_arena[:self._gn2_used].zero_)
         return n
@@ -351,7 +353,7 @@ class Schedule:
 
     def _conv_desc(self, Hi, Wi, Ci, Ho, Wo, stride, pad, ups, ldx, mode=1):
         return dict(mode=mode, Hi=Hi, Wi=Wi, Ci=Ci, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad, pad_l=pad, ups=ups,
-                    ldx=ldx, korder=1 if packing.KORDER_CM else 0)
+                    ldx=ldx, korder=1 if (packing.KORDER_CM and Ci % 64 == 0) else 0)  # the packing's own predicate
 
     def _resnet(self, x: T, cin, cout, name, w, out_view, h, wd, need_dx=True):
         """ResnetBlock2D: GN+SiLU -> conv1 (+ time-embedding row add) -> GN+SiLU -> conv2 + shortcut."""

@@ -57,8 +57,7 @@ class UNetEngine(Schedule):
         if autotune:
             self.autotune()
         self.bind_workspace()
-        if fuse_gn:
-            self.fuse_gn_stats()
+        self.fuse_gn_stats(fuse=fuse_gn)
 
     # ------------------------------------------------------------------ time embedding
     def _pack_time_weights(self, w):
