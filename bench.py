@@ -241,7 +241,7 @@ def cpu_baseline(args):
     pix = (res / 512.0) ** 2
     sample_gf = ((1116.7 + 803.3 + 929.4) * pix + 212.8 + 216.0) * B
     bench_gf = ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512.0) ** 2
-    est_steps_per_s = (sample_gf / dt) / bench_gf
+    est_steps_per_s = 1.0 / dt if (B, res) == (args.batch, args.resolution) else (sample_gf / dt) / bench_gf
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -255,7 +255,7 @@ def cpu_baseline(args):
             "sample": f"oracle/sd_ref.py fp32 torch-CPU restatement (diffusers not installable): 1 warm-up ({warm:.1f}s) + "
                       f"{len(times)} timed train steps (fwd+bwd) at bs={B} {res}x{res}, mean {dt:.2f}s min {min(times):.2f}s "
                       f"({sample_gf / dt:.1f} GFLOP/s, loss {loss_v:.4f}); "
-                      + ("the bench's own batch size and resolution, nothing scaled; " if abs(bench_gf / sample_gf - 1) < 1e-9 else
+                      + ("the bench's own batch size and resolution, nothing scaled; " if (B, res) == (args.batch, args.resolution) else
                          f"bs={B} instead of the bench's bs={args.batch} to stay inside the wall-clock bound, scaled to "
                          f"bs={args.batch} {args.resolution}x{args.resolution} by algorithmic FLOPs (x{bench_gf / sample_gf:.2f}); ")
                       + f"torch.get_num_threads()={torch.get_num_threads()}, "

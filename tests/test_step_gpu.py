@@ -264,9 +264,8 @@ def test_full_size_matches_oracle(cfg_name, B, H, W, with_view):
     torch.cuda.synchronize()
     loss_gpu = eng.loss()
     grads_gpu = (eng.grads / eng.scaler[0]).float().cpu()
-    pred_gpu = eng.unet.pred.float().cpu()
+    pred_gpu = eng.unet.pred.float().cpu().view(B, H // 8, W // 8, 4).permute(0, 3, 1, 2)  # pixel-major -> NCHW
     lat_gpu = eng.latents.cpu()
-    ctx_gpu = eng.unet.ctx_k.float().cpu()
     # ---- oracle on the host: fp16-rounded weights (what the GPU holds), fp32 arithmetic ----
     r16 = lambda d: {k: ((v.half().float() if v.dim() >= 2 and "embedding" not in k else v.float()).cpu())
                      for k, v in d.items()}
@@ -292,8 +291,8 @@ def test_full_size_matches_oracle(cfg_name, B, H, W, with_view):
     gerr = ((grads_gpu - ref_g).norm() / ref_g.norm()).item()
     lat = ((lat_gpu - aux["latents"]).norm() / aux["latents"].norm()).item()
     pred_o = aux["pred"].detach()
-    pred_rel = ((pred_gpu.reshape(pred_o.shape) - pred_o).norm() / pred_o.norm()).item()
-    pred_max = (pred_gpu.reshape(pred_o.shape) - pred_o).abs().max().item()
+    pred_rel = ((pred_gpu - pred_o).norm() / pred_o.norm()).item()
+    pred_max = (pred_gpu - pred_o).abs().max().item()
     print(f"[full size oracle {cfg_name} {H}x{W} bs{B} view={with_view}] oracle fwd+bwd {dt:.1f}s on "
           f"{torch.get_num_threads()} threads; loss gpu {loss_gpu:.6f} oracle {loss.item():.6f} rel {rel:.2e}; latents "
           f"rel {lat:.2e}; pred rel {pred_rel:.2e} max-abs {pred_max:.2e} (rms {pred_o.pow(2).mean().sqrt():.3f}); "
