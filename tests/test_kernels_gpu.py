@@ -49,7 +49,7 @@ def check(name, got, ref, tol, elem_k=ELEM_K):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 101, 102, 103, 104, 105])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 101, 102, 103, 104, 105])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (128, 64, 64), (77 * 4, 1280, 768), (1000, 8, 192)])
 def test_gemm_plain(hint, M, N, K):
     ops = _ops()
@@ -109,9 +109,10 @@ def test_gemm_f32_out_rowadd_act_batch():
     check("gemm batched", outb, Ab.float() @ B.float().t(), 2e-3)
 
 
+@pytest.mark.parametrize("hint", [3, 16])
 @pytest.mark.parametrize("split", [2, 3, 5, 0])
 @pytest.mark.parametrize("f32", [False, True])
-def test_gemm_split_k(split, f32):
+def test_gemm_split_k(split, f32, hint):
     """split-K partials + reduce kernel must reproduce the fused epilogue (bias, row-add, residual)."""
     ops = _ops()
     M, N, K = 200, 328, 64 * 24
@@ -122,23 +123,24 @@ def test_gemm_split_k(split, f32):
     if f32:
         res = rnd(M, N, seed=44, dtype=torch.float32)
         out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
-        ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), workspace=ws, split_k=split, tile_hint=3)
+        ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), workspace=ws, split_k=split, tile_hint=hint)
         ref = A.float() @ B.float().t() + bias + res
     else:
         res = rnd(M, N, seed=44)
         radd = rnd(M // 50, N, seed=45)
         out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
         ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), rowadd=radd.to(DEV), rows_per_group=50,
-                 workspace=ws, split_k=split, tile_hint=3)
+                 workspace=ws, split_k=split, tile_hint=hint)
         ref = (A.float() @ B.float().t() + bias).half().float() + radd.float().repeat_interleave(50, 0) + res.float()
     torch.cuda.synchronize()
     check(f"gemm split_k={split} f32={f32}", out, ref, 2e-3)
 
 
+@pytest.mark.parametrize("hint", [3, 16])
 @pytest.mark.parametrize("act", [1, 2, 3])
 @pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("N", [328, 324])
-def test_gemm_gate_and_second_output(act, split, N):
+def test_gemm_gate_and_second_output(act, split, N, hint):
     """epilogue extensions of the CLIP MLP: out = (A@B^T + bias) * act'(pre), out2 = act2(out)
     (transformers CLIPMLP forward/backward, modeling_clip.py) in the fused and the split-K reduce epilogue."""
     ops = _ops()
@@ -152,7 +154,7 @@ def test_gemm_gate_and_second_output(act, split, N):
     out = torch.zeros(M, ldp, dtype=torch.float16, device=DEV)[:, :N]
     out2 = torch.zeros(M, ldp, dtype=torch.float16, device=DEV)[:, :N]
     ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), gate=pre.to(DEV)[:, :N], gate_act=act, out2=out2, act2=act,
-             workspace=ws, split_k=split, tile_hint=3)
+             workspace=ws, split_k=split, tile_hint=hint)
     torch.cuda.synchronize()
     x = pre[:, :N].float().requires_grad_(True)
     fn = {1: F.silu, 2: lambda t: t * torch.sigmoid(1.702 * t), 3: F.gelu}[act]
@@ -162,7 +164,7 @@ def test_gemm_gate_and_second_output(act, split, N):
     check(f"gemm out2 act{act} split{split}", out2, fn(out.float().cpu()), 1e-3)
 
 
-@pytest.mark.parametrize("hint", [0, 1, 3, 5, 7, 10, 12])
+@pytest.mark.parametrize("hint", [0, 1, 3, 5, 7, 10, 12, 16])
 @pytest.mark.parametrize("M,C", [(300, 64), (1024, 320)])
 def test_gemm_geglu_epilogues(hint, M, C):
     """diffusers FeedForward GEGLU (h, g = proj(x).chunk(2); h * gelu(g)) fused into the GEMM epilogues
@@ -203,7 +205,7 @@ def test_gemm_geglu_epilogues(hint, M, C):
                  workspace=torch.empty(2 * M * 2 * F4, dtype=torch.float32, device=DEV))
 
 
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9, 14])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9, 14, 16])
 @pytest.mark.parametrize("Bn,HW,C", [(4, 64, 320), (2, 256, 128), (3, 576, 640), (2, 4096, 32 * 4)])
 def test_gemm_groupnorm_sums_and_fused_apply(hint, Bn, HW, C):
     """GroupNorm statistics accumulated by the GEMM epilogue (rows = Bn images of HW pixels, 32 groups) and the
@@ -249,7 +251,7 @@ def _nhwc(x):
 
 @pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
 @pytest.mark.parametrize("case", ["s1", "s2p1", "s2vae", "ups"])
-@pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 13, 15, 101, 103])
+@pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 13, 15, 16, 101, 103])
 def test_conv3x3_fwd(case, hint, korder):
     """both K orders of the implicit GEMM (vneti_gemm_desc.conv_korder): (tap, channel) and (64-channel chunk, tap,
     channel); two chunks so that the orders really differ"""
@@ -281,10 +283,11 @@ def test_conv3x3_fwd(case, hint, korder):
     check(f"conv {case} hint{hint} korder{korder}", out.view(Bn, Ho, Wo, Co), _nhwc(ref), 2e-3)
 
 
+@pytest.mark.parametrize("hint", [3, 16])
 @pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
 @pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("stride,vae", [(1, False), (2, False), (2, True)])
-def test_conv3x3_dgrad(stride, vae, split, korder):
+def test_conv3x3_dgrad(stride, vae, split, korder, hint):
     ops = _ops()
     from view_neti_amd import packing
     Bn, Ci, Co, H, W = 2, 64, 128, 12, 20
@@ -303,7 +306,7 @@ def test_conv3x3_dgrad(stride, vae, split, korder):
     conv = dict(mode=2, Hi=Ho, Wi=Wo, Ci=Co, Ho=H, Wo=W, stride=stride, pad_t=pt, pad_l=pt, ups=0, ldx=Co, korder=korder)
     ws = torch.empty(4 * Bn * H * W * Ci, dtype=torch.float32, device=DEV)
     ops.gemm(_nhwc(dy).to(DEV), packing.conv3x3_dgrad(w, cm=bool(korder)).to(DEV), dx, conv=conv, M=Bn * H * W,
-             workspace=ws, split_k=split, tile_hint=3)
+             workspace=ws, split_k=split, tile_hint=hint)
     torch.cuda.synchronize()
     check(f"conv dgrad s{stride} vae={vae} split{split} korder{korder}", dx.view(Bn, H, W, Ci), _nhwc(x.grad), 2e-3)
 

@@ -1,0 +1,580 @@
+// 256x256 "8-phase" ping-pong tile of the GEMM / implicit-GEMM convolution family (gfx950 / CDNA4).
+//
+//   C[M,N] = epilogue( alpha * A[M,K] . B[N,K]^T )      same contract, argument block and epilogues as gemm_conv.hip
+//
+// Carries the same launches as the generic 256x256 tile (tile_hint 5) — the large convolutions of the VAE encoder and
+// the UNet's 64x64 level, the CLIP projections; reference: the diffusers modules driven from training/coach.py:165-169,
+// 197-198 and the to_q/to_k/to_v/to_out calls of models/xti_attention_processor.py:30-55 — with a different main loop
+// (the structure /opt/skills/guides/cdna_hip_programming.md calls the 256^2 8-phase template):
+//
+//   * 8 waves (2 x 4), two per SIMD.  A wave owns four 64x32 quadrants of C: rows {h*128 + wr*64 .. +64}, columns
+//     {j*128 + wc*32 .. +32}, h, j in {0,1} — so every wave reads every "half tile" (A0, A1 = rows 0..127 / 128..255 of
+//     the block's A panel, B0, B1 likewise), and a half tile is the unit of staging and of register loading.
+//   * LDS: 2 K-tile buffers x 4 half tiles x 16 KiB = 128 KiB, 128-byte rows with the 16-byte chunks XOR-swizzled
+//     (conflict-free ds_read_b128), filled by LDS-DMA (buffer_load ... lds; swizzle on the source side, out-of-range
+//     offsets return zeros = conv padding and M/N/K tails).
+//   * a K-tile (BK = 64) is 4 phases, one quadrant of 16 x v_mfma_f32_16x16x32_f16 each:
+//         P0: read A0(t)   [8 ds_read_b128]   stage A1(t+1)   C00 += A0.B0
+//         P1: read B1(t)   [4]                stage B0(t+2)   C01 += A0.B1
+//         P2: read A1(t)   [8]                stage A0(t+2)   C10 += A1.B0
+//         P3: read B0(t+1) [4]                stage B1(t+2)   C11 += A1.B1
+//     each phase = { ds_reads, 2 LDS-DMAs, s_waitcnt vmcnt(10), s_barrier, lgkmcnt(0), 16 MFMA at raised priority,
+//     s_barrier }.  The two wave rows (wr = 0 / 1) run one barrier apart, so on every SIMD one wave issues its reads and
+//     DMAs while its partner runs its MFMAs.
+//   * a half tile is staged six phases before it is read and five stagings stay in flight across every wait
+//     (vmcnt never 0 in the loop): position 7 + p of the staging stream is issued in phase p, the wait of phase p
+//     retires position p + 2, which phase p + 1 reads.  RAW: wait in phase p (before its first barrier), read in
+//     phase p + 1.  WAR: a slot is restaged two phases after the phase that issued its last reads (the staggered wave
+//     row retires them one barrier later than the other).
+//   * epilogue: the gemm_conv.hip one (C tile through LDS, bias / row-add / residual / activation / gate / GEGLU /
+//     GroupNorm sums, EPI levels), split-K partials straight from the accumulators.
+#include "common.h"
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, NT = 512;
+constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 64 halfs
+constexpr int BUF_BYTES = 4 * HALF_BYTES;  // A0 A1 B0 B1 of one K-tile
+constexpr int CS_LD = BN + 8;
+constexpr int CS_BYTES = BM * CS_LD * 2;
+constexpr int LDS_BYTES = CS_BYTES > 2 * BUF_BYTES ? CS_BYTES : 2 * BUF_BYTES;
+constexpr int GN_IMG = 5, GN_NG = BN / 4 + 2;
+
+// lab build (-DVN_GEMM8_STAMP, tools/lab/gemm8_stamps.py): thread 0 of every block records s_memtime at the section
+// boundaries into the (otherwise unused) split-K workspace
+#ifdef VN_GEMM8_STAMP
+#define VN_STAMP(i)                                                                                       \
+  do {                                                                                                    \
+    if (tid == 0 && g.ws) reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define VN_STAMP(i)
+#endif
+
+#define VN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define VN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int EPI, bool CONV>
+__global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
+  const half_t* const e_gate = EPI == 2 ? g.gate_src : nullptr;
+  half_t* const e_C2 = EPI == 2 ? g.C2 : nullptr;
+  const int e_geglu = EPI == 2 ? g.geglu : 0;
+  const int e_act = EPI == 2 ? g.act : 0;
+  float* const e_gn_sums = EPI >= 1 ? g.gn_sums : nullptr;
+  const half_t* const e_rowadd = EPI >= 1 ? g.rowadd : nullptr;
+  const int e_conv = CONV ? g.conv_mode : 0;
+  constexpr int GN_BYTES = EPI == 0 ? 0 : GN_IMG * GN_NG * 2 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + GN_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  VN_STAMP(0);
+
+  // XCD-aware tile mapping (bijective for any tile count): consecutive ids on one XCD sweep N for a fixed M panel
+  int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid / g.tiles_n;
+  const int tile_n = bid - tile_m * g.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int bz = blockIdx.y;
+  const int kz = blockIdx.z;
+
+  const half_t* Ab = g.A + (long long)bz * g.strideA;
+  const half_t* Bb = g.B + (long long)bz * g.strideB;
+  const __amdgpu_buffer_rsrc_t rsA = vn_make_rsrc(Ab, g.a_bytes);
+  const __amdgpu_buffer_rsrc_t rsB = vn_make_rsrc(Bb, g.b_bytes);
+
+  // ---- staging geometry: one LDS-DMA of the block covers 64 rows x 128 B; a half tile is two of them (j = 0, 1).
+  // Lane -> (row lrow = tid / 8 of the 64, 16-byte slot tid % 8); the slot is lane-linear in LDS, so the swizzle
+  // (chunk ^ ((row >> 1) & 7)) is applied to the source chunk.  Row slot r = 2 * h + j is block row h*128 + j*64 + lrow.
+  //
+  // Source offset of row slot r for a K-tile = a_base[r] + (a wave-uniform byte offset of the tile), valid where bit
+  // `tap` of a_mask[r] is set, else VN_OOB (zeros):
+  //   plain GEMM      a_base = row * lda * 2 + chunk,  tile offset = k0 * 2,  mask = 1 for rows < M
+  //   conv, gather    a_base = offset of input pixel (oy*stride - pad, ox*stride - pad) of the row's output pixel,
+  //                   tile offset = +(dy * Wi + dx) * pixel stride + channel offset, mask bit (3*dy + dx) = that tap is
+  //                   inside the image (the zero padding)
+  //   conv, dgrad s1  a_base = offset of pixel (oy + pad, ox + pad), tile offset = -(dy * Wi + dx) * ... (transposed
+  //                   gather with unflipped taps), mask likewise
+  // so the per-tile address work is scalar, plus an and / compare / add / select per row — no tap-boundary recompute.
+  // (Fused upsampling and the stride-2 transposed gather are not linear in the tap: those launches stay on tile 5.)
+  const int lrow = tid >> 3;
+  const int gchunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  int a_base[4];
+  uint32_t a_mask[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + (r >> 1) * 128 + (r & 1) * 64 + lrow;
+    const bool ok = m < g.M;
+    if constexpr (!CONV) {
+      a_base[r] = (int)((long long)m * g.lda * 2) + gchunk * 16;
+      a_mask[r] = ok ? 1u : 0u;
+    } else {
+      const int hw = g.Ho * g.Wo;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int oy = rem / g.Wo;
+      const int ox = rem - oy * g.Wo;
+      const int py = e_conv == 1 ? oy * g.stride - g.pad_t : oy + g.pad_t;
+      const int px = e_conv == 1 ? ox * g.stride - g.pad_l : ox + g.pad_l;
+      a_base[r] = ((b * g.Hi + py) * g.Wi + px) * g.ldx2 + gchunk * 16;
+      uint32_t mask = 0;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - 3 * (tap / 3);
+        const int iy = e_conv == 1 ? py + dy : py - dy, ix = e_conv == 1 ? px + dx : px - dx;
+        if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) mask |= 1u << tap;
+      }
+      a_mask[r] = ok ? mask : 0u;
+    }
+  }
+  uint32_t b_base[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + (r >> 1) * 128 + (r & 1) * 64 + lrow;
+    b_base[r] = (n < g.N) ? (uint32_t)((long long)n * g.ldb * 2) + gchunk * 16 : VN_OOB;  // + k0 * 2 stays out of range
+  }
+
+  const int nk_total = g.K / 64;
+  const int kt_begin = kz * g.kt_per_split;
+  const int kt_end = min(nk_total, kt_begin + g.kt_per_split);
+  const int T = kt_end - kt_begin;
+
+  // ---- the four staging streams (A0, A1, B0, B1): the next K-tile each will fetch (all wave-uniform) ----
+  int a_kt[2] = {kt_begin, kt_begin}, b_kt[2] = {kt_begin, kt_begin};
+  int a_tap[2], a_ci0[2];  // conv: tap and first channel of the stream's next tile (tap-major K order)
+  {
+    int tap = 0, ci0 = 0;
+    if constexpr (CONV) {
+      tap = (kt_begin * 64) / g.Ci;
+      ci0 = kt_begin * 64 - tap * g.Ci;
+    }
+    a_tap[0] = a_tap[1] = tap;
+    a_ci0[0] = a_ci0[1] = ci0;
+  }
+  // A staging is split in two: prep*() computes the two source offsets of the stream's next K-tile (and advances the
+  // stream) — it runs inside the PREVIOUS phase's MFMA block, where VALU / SALU issue beside the matrix pipe for free —
+  // and issue*() is just the two LDS-DMAs, so a phase's load section stays shorter than its partner's 16 MFMAs.
+  const int tap_step = (e_conv == 2 ? -1 : 1) * g.ldx2;
+  uint32_t nxt[2];
+  auto prepA = [&](const int h) {
+    const bool live = a_kt[h] < kt_end;  // stagings past the end keep the vmcnt bookkeeping uniform and fetch nothing
+    int soff;
+    uint32_t tapbit;
+    if constexpr (!CONV) {
+      soff = a_kt[h] * 128;
+      tapbit = live ? 1u : 0u;
+    } else {
+      const int tap = a_tap[h];
+      const int dy = (tap * 11) >> 5;  // tap / 3 for tap < 9
+      const int dx = tap - 3 * dy;
+      soff = (dy * g.Wi + dx) * tap_step + a_ci0[h] * 2;
+      tapbit = live ? (1u << tap) : 0u;
+      a_ci0[h] += 64;
+      if (a_ci0[h] == g.Ci) {
+        a_ci0[h] = 0;
+        a_tap[h] += 1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) nxt[j] = (a_mask[2 * h + j] & tapbit) ? (uint32_t)(a_base[2 * h + j] + soff) : VN_OOB;
+    a_kt[h] += 1;
+  };
+  auto prepB = [&](const int h) {
+    const bool live = b_kt[h] < kt_end;
+    const uint32_t soff = (uint32_t)b_kt[h] * 128u, dead = live ? 0u : VN_OOB;  // | VN_OOB: beyond any buffer (< 2 GiB)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) nxt[j] = (b_base[2 * h + j] + soff) | dead;
+    b_kt[h] += 1;
+  };
+  auto issueA = [&](const int h, const int buf) {
+    char* dst = smem + buf * BUF_BYTES + h * HALF_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(rsA, dst + j * 8192, nxt[j]);
+  };
+  auto issueB = [&](const int h, const int buf) {
+    char* dst = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(rsB, dst + j * 8192, nxt[j]);
+  };
+
+  // ---- fragment reads: lane (frow = row of the 16-row block, fq = its 8-wide k chunk inside a k32 sub-step) ----
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  const int fkey = (frow >> 1) & 7;
+  // byte offsets (buffer 0) of this lane's chunk for k sub-step 0 / 1; the K-tile buffer is toggled with ^ BUF_BYTES
+  int rdA[2], rdB[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int ch = ((s * 4 + fq) ^ fkey) << 4;
+    rdA[s] = (wr * 64 + frow) * 128 + ch;
+    rdB[s] = 2 * HALF_BYTES + (wc * 32 + frow) * 128 + ch;
+  }
+  half8 af[4][2], bf0[2][2], bf1[2][2];
+  auto readA = [&](const int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        af[i][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdA[s] + h * HALF_BYTES + i * 2048));
+  };
+  auto readB0 = [&](const int flip) {  // flip = BUF_BYTES: from the other K-tile buffer
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) bf0[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + (rdB[s] ^ flip) + jb * 2048));
+  };
+  auto readB1 = [&]() {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        bf1[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdB[s] + HALF_BYTES + jb * 2048));
+  };
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) acc[h][j][i][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one quadrant: 16 MFMAs; operands swapped (D[row = n][col = m]) so a lane owns 4 consecutive n of one m.  PREP = the
+  // address work of the NEXT phase's staging, free to be scheduled between the MFMAs.
+#define VN_MMA(H, J, BF, PREP)                                                                                 \
+  do {                                                                                                         \
+    VN_WAIT_LGKM0();                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    PREP;                                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                \
+        _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) acc[H][J][i][jb] =                                    \
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[jb][s], af[i][s], acc[H][J][i][jb], 0, 0, 0);           \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+  } while (0)
+#define VN_PHASE_SYNC()                    \
+  do {                                     \
+    VN_WAIT_VM(10);                        \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+#define VN_PHASE_END()                     \
+  do {                                     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+
+  // ---- prologue: tile 0 and three half tiles of tile 1 (stream positions 0..6) ----
+  prepB(0);
+  issueB(0, 0);
+  prepA(0);
+  issueA(0, 0);
+  prepB(1);
+  issueB(1, 0);
+  prepA(1);
+  issueA(1, 0);
+  prepB(0);
+  issueB(0, 1);
+  prepA(0);
+  issueA(0, 1);
+  prepB(1);
+  issueB(1, 1);
+  prepA(1);        // A1 of tile 1: issued in phase 0
+  VN_WAIT_VM(10);  // positions 0, 1 (B0, A0 of tile 0) have landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  VN_STAMP(1);
+  readB0(0);
+  VN_WAIT_LGKM0();  // retired before the stagger barrier: the slot is restaged in phase 1
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+  __builtin_amdgcn_sched_barrier(0);
+
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    // P0
+    readA(0);
+    issueA(1, cur ^ 1);
+    VN_PHASE_SYNC();
+    VN_MMA(0, 0, bf0, prepB(0));
+    VN_PHASE_END();
+    // P1
+    readB1();
+    issueB(0, cur);
+    VN_PHASE_SYNC();
+    VN_MMA(0, 1, bf1, prepA(0));
+    VN_PHASE_END();
+    // P2
+    readA(1);
+    issueA(0, cur);
+    VN_PHASE_SYNC();
+    VN_MMA(1, 0, bf0, prepB(1));
+    VN_PHASE_END();
+    // P3
+    readB0(BUF_BYTES);
+    issueB(1, cur);
+    VN_PHASE_SYNC();
+    VN_MMA(1, 1, bf1, prepA(1));
+    VN_PHASE_END();
+    cur ^= 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      rdA[s] ^= BUF_BYTES;
+      rdB[s] ^= BUF_BYTES;
+    }
+  }
+  VN_STAMP(2);
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the (zero-filling) stagings past the end must have landed
+  __syncthreads();                                                // before the epilogue reuses the buffers as its C tile
+#undef VN_MMA
+#undef VN_PHASE_SYNC
+#undef VN_PHASE_END
+
+  // acc[h][j][i][jb][e]  <->  block row h*128 + wr*64 + i*16 + frow, block column j*128 + wc*32 + jb*16 + 4*fq + e
+  // ---- split-K: raw f32 partials straight to the workspace ----
+  if (g.ksplit > 1) {
+    float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) {
+            const int m = m0 + h * 128 + wr * 64 + i * 16 + frow;
+            const int n = n0 + j * 128 + wc * 32 + jb * 16 + 4 * fq;
+            if (m < g.M && n < g.N) {
+              float* p = ws + (long long)m * g.N + n;
+              if (n + 4 <= g.N && (g.N & 3) == 0) {
+                *reinterpret_cast<f32x4*>(p) = acc[h][j][i][jb];
+              } else {
+                for (int e = 0; e < 4 && n + e < g.N; ++e) p[e] = acc[h][j][i][jb][e];
+              }
+            }
+          }
+    return;
+  }
+
+  if (e_gn_sums) {
+    float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
+    for (int i = tid; i < GN_IMG * GN_NG * 2; i += NT) gacc[i] = 0.f;
+  }
+  // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ----
+  {
+    const __amdgpu_buffer_rsrc_t rsBias = vn_make_rsrc(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
+    f32x4 bv[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+        bv[j][jb] = __builtin_bit_cast(f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + j * 128 + wc * 32 + jb * 16 + 4 * fq) * 4u));
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) {
+            const int ml = h * 128 + wr * 64 + i * 16 + frow;
+            const int nl = j * 128 + wc * 32 + jb * 16 + 4 * fq;
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)apply_act(acc[h][j][i][jb][e] * g.alpha + bv[j][jb][e], e_act);
+            *reinterpret_cast<half4*>(smem + ((size_t)ml * CS_LD + nl) * 2) = o;
+          }
+  }
+  __syncthreads();
+  VN_STAMP(3);
+
+  // ---- epilogue phase 2: coalesced row-major stores with the fused operands (same code as gemm_conv.hip's f16 path) ----
+  half_t* Cb = reinterpret_cast<half_t*>(g.C) + (long long)bz * g.strideC;
+  const half_t* Rb = reinterpret_cast<const half_t*>(g.resid);
+  if (Rb) Rb += (long long)bz * g.strideC;
+  constexpr int CPR = BN / 8;
+  static_assert(NT % CPR == 0 && CPR <= 32 && (BM * CPR) % NT == 0, "a thread keeps one 8-column chunk over all its rows");
+  float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
+  const bool gn = e_gn_sums != nullptr;
+  const int gn_img0 = gn ? m0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
+  const int gn_c = n0 + (tid % CPR) * 8;
+  const int gn_glo = gn ? gn_c / g.gn_cpg : 0;
+  const int gn_split = gn ? (gn_glo + 1) * g.gn_cpg - gn_c : 8;  // columns [0, split) of the chunk are in group lo
+  int gn_img = -1;
+  float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
+  auto gn_flush = [&]() {
+    const int iref = __builtin_amdgcn_readfirstlane(gn_img);
+    const bool uni = __all(gn_img == iref) && iref >= 0;
+    if (uni) {
+#pragma unroll
+      for (int off = 32; off >= CPR; off >>= 1) {
+        s_lo += __shfl_xor(s_lo, off);
+        q_lo += __shfl_xor(q_lo, off);
+        s_hi += __shfl_xor(s_hi, off);
+        q_hi += __shfl_xor(q_hi, off);
+      }
+    }
+    if (gn_img >= 0 && (!uni || lane < CPR)) {
+      float* a = gacc + ((gn_img - gn_img0) * GN_NG + (gn_glo - gn_g0t)) * 2;
+      atomicAdd(a, s_lo);
+      atomicAdd(a + 1, q_lo);
+      if (gn_split < 8) {
+        atomicAdd(a + 2, s_hi);
+        atomicAdd(a + 3, q_hi);
+      }
+    }
+    s_lo = q_lo = s_hi = q_hi = 0.f;
+  };
+  for (int idx = tid; idx < BM * CPR; idx += NT) {  // BM * CPR is a multiple of NT: uniform trip count
+    const int r = idx / CPR, c = (idx - r * CPR) * 8;
+    const int m = m0 + r, n = n0 + c;
+    const bool valid = m < g.M && n < g.N;
+    if (gn) {
+      const int img = valid ? m / g.gn_hw : gn_img;
+      if (__any(img != gn_img)) {
+        gn_flush();
+        gn_img = img;
+      }
+    }
+    if (!valid) continue;
+    half8 v = as_half8(*reinterpret_cast<const u32x4*>(smem + ((size_t)r * CS_LD + c) * 2));
+    const half_t* radd = e_rowadd ? e_rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + n : nullptr;
+    if (n + 8 <= g.N) {
+      if (radd) {
+        const half8 t = *reinterpret_cast<const half8*>(radd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)t[e]);
+      }
+      if (Rb) {
+        const half8 rr = *reinterpret_cast<const half8*>(Rb + (long long)m * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+      }
+      if (e_geglu == 2) {
+        // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]
+        const half_t* pp = e_gate + (long long)m * g.ld_gate + 2 * n;
+        half_t* dp = Cb + (long long)m * g.ldc + 2 * n;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const half8 pre = *reinterpret_cast<const half8*>(pp + 8 * c2);
+          half8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = (float)v[4 * c2 + e], hh = (float)pre[e], gg = (float)pre[4 + e];
+            float cdf, xpdf;
+            vn_gelu_parts(gg, cdf, xpdf);
+            o[e] = (half_t)(d * gg * cdf);
+            o[4 + e] = (half_t)(d * hh * (cdf + xpdf));
+          }
+          *reinterpret_cast<half8*>(dp + 8 * c2) = o;
+        }
+        continue;
+      }
+      if (e_gate) {
+        const half8 pre = *reinterpret_cast<const half8*>(e_gate + (long long)m * g.ld_gate + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)pre[e], g.gate_act));
+      }
+      *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
+      if (e_geglu == 1) {
+        half4 o2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o2[e] = (half_t)((float)v[e] * vn_gelu_erf((float)v[4 + e]));
+        *reinterpret_cast<half4*>(e_C2 + (long long)m * g.ldc2 + (n >> 1)) = o2;
+      }
+      if (gn) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (float)v[e];
+          if (e < gn_split) {
+            s_lo += x;
+            q_lo += x * x;
+          } else {
+            s_hi += x;
+            q_hi += x * x;
+          }
+        }
+      }
+      if (e_C2 && e_geglu == 0) {
+        half8 o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o2[e] = (half_t)apply_act((float)v[e], g.act2);
+        *reinterpret_cast<half8*>(e_C2 + (long long)m * g.ldc2 + n) = o2;
+      }
+    } else {
+      for (int e = 0; e < 8 && n + e < g.N; ++e) {
+        float x = (float)v[e];
+        if (radd) x = (float)(half_t)(x + (float)radd[e]);
+        if (Rb) x = (float)(half_t)(x + (float)Rb[(long long)m * g.ldr + n + e]);
+        if (e_gate) x = (float)(half_t)(x * act_grad((float)e_gate[(long long)m * g.ld_gate + n + e], g.gate_act));
+        Cb[(long long)m * g.ldc + n + e] = (half_t)x;
+        if (e_C2) e_C2[(long long)m * g.ldc2 + n + e] = (half_t)apply_act((float)(half_t)x, g.act2);
+        if (gn) {
+          const float xs = (float)(half_t)x;
+          if (e < gn_split) {
+            s_lo += xs;
+            q_lo += xs * xs;
+          } else {
+            s_hi += xs;
+            q_hi += xs * xs;
+          }
+        }
+      }
+    }
+  }
+  if (gn) {
+    gn_flush();
+    __syncthreads();
+    const int slot = tile_m % g.gn_slots;
+    for (int i = tid; i < GN_IMG * GN_NG; i += NT) {
+      const float sv = gacc[2 * i], qv = gacc[2 * i + 1];
+      if (sv == 0.f && qv == 0.f) continue;
+      const int img = gn_img0 + i / GN_NG, grp = gn_g0t + i % GN_NG;
+      float* dst = e_gn_sums + (((long long)img * g.gn_slots + slot) * g.gn_G + grp) * 2;
+      unsafeAtomicAdd(dst, sv);  // hardware global_atomic_add_f32
+      unsafeAtomicAdd(dst + 1, qv);
+    }
+  }
+#ifdef VN_GEMM8_STAMP
+  VN_STAMP(4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VN_STAMP(5);
+#endif
+}
+
+inline int epilogue_level8(const GemmArgs& g) {
+  if (g.gate_src || g.C2 || g.geglu || g.act) return 2;
+  return (g.gn_sums || g.rowadd) ? 1 : 0;
+}
+
+}  // namespace
+
+// f16 output only; the caller (vneti_gemm_f16) has validated the descriptor, set ksplit / kt_per_split and launches the
+// split-K reduce itself.  Returns VNETI_EUNSUP for what this tile does not carry (f32 output, chunk-major conv K order).
+int vneti_launch_gemm8(void* gemm_args, hipStream_t st) {
+  GemmArgs& g = *reinterpret_cast<GemmArgs*>(gemm_args);
+  if (g.out_f32 || (g.conv_mode && (g.korder || g.ups || (g.conv_mode == 2 && g.stride == 2)))) return VNETI_EUNSUP;
+  g.tiles_m = cdiv(g.M, BM);
+  g.tiles_n = cdiv(g.N, BN);
+  const dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit), block(NT);
+  const int epi = epilogue_level8(g);
+#define VN_GO(E, C) hipLaunchKernelGGL((gemm8_kernel<E, C>), grid, block, 0, st, g)
+  if (g.conv_mode) {
+    if (epi == 2) VN_GO(2, true); else if (epi == 1) VN_GO(1, true); else VN_GO(0, true);
+  } else {
+    if (epi == 2) VN_GO(2, false); else if (epi == 1) VN_GO(1, false); else VN_GO(0, false);
+  }
+#undef VN_GO
+  return vneti_check_launch("gemm8_kernel");
+}

@@ -28,77 +28,10 @@
 // 256 CUs (M = 256/1024 with K up to 23040).  The kernel is instantiated per epilogue feature group (EPI) and with /
 // without the implicit-im2col paths (CONV): code size is a per-launch cost (see the template's comment).
 #include "common.h"
+#include "gemm_args.h"
 #include "../../include/vneti.h"
 
 namespace {
-
-struct GemmArgs {
-  const half_t* A;
-  const half_t* B;
-  void* C;
-  const float* bias;
-  const half_t* rowadd;
-  const void* resid;
-  float* ws;
-  const half_t* gate_src;
-  half_t* C2;
-  long long ld_gate, ldc2;
-  int gate_act, act2;
-  float* gn_sums;  // [image][slot][G][2] running (sum, sum of squares) of the f16 output, see vneti_gemm_desc
-  int gn_hw, gn_cpg, gn_G, gn_slots;
-  int geglu;  // 1: C2 = h * gelu(g) of the interleaved tile; 2: C[M][2N] = GEGLU backward against gate_src (see vneti.h)
-  long long lda, ldb, ldc, ld_rowadd, ldr;
-  long long strideA, strideB, strideC;
-  uint32_t a_bytes, b_bytes;
-  int M, N, K;
-  int rows_per_group;
-  float alpha;
-  int act;
-  int out_f32;
-  int batch, ksplit, kt_per_split;
-  // implicit conv
-  int conv_mode;  // 0 plain, 1 forward gather, 2 transposed gather (dgrad)
-  int Hi, Wi, Ci, Ho, Wo, stride, pad_t, pad_l, ups;
-  int ldx2;  // pixel stride in bytes
-  int korder;  // 0: K = (tap, ci); 1: K = (ci / 64, tap, ci % 64)
-  int tiles_m, tiles_n;
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  switch (act) {
-    case 1: return vn_silu(v);
-    case 2: return vn_quick_gelu(v);
-    case 3: return vn_gelu_erf(v);
-    default: return v;
-  }
-}
-// d act(x) / dx
-__device__ __forceinline__ float act_grad(float f, int act) {
-  if (act == 2) {
-    float s = vn_sigmoid(1.702f * f);
-    return s * (1.f + 1.702f * f * (1.f - s));
-  } else if (act == 3) {
-    return vn_gelu_erf_grad(f);
-  }
-  float s = vn_sigmoid(f);
-  return s * (1.f + f * (1.f - s));
-}
-
-// LDS tile of R rows x 64 halfs (128 B rows), 16-byte chunks XOR-swizzled so that a
-// ds_read_b128 by 16 lanes on consecutive rows touches 16 distinct 16-B slots.
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-// one LDS-DMA instruction: 64 lanes x 16 B land at lds_dst + lane*16 (lds_dst wave-uniform).
-// The builtin only exists in the device compilation pass.
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t off) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, off, 0, 0, 0);
-#else
-  (void)rs; (void)lds_dst; (void)off;
-#endif
-}
 
 // EPI selects how much of the fused epilogue is compiled in: 0 = bias + residual (most launches), 1 = + time-embedding
 // row-add and GroupNorm sums (the resnet convolutions, every VAE conv), 2 = + activation, gate, second output, GEGLU.
@@ -810,8 +743,10 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
 struct TileDims {
   int bm, bn;
 };
-constexpr TileDims kTiles[16] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128}, {256, 256}, {256, 128}, {256, 128},
-                                {256, 128}, {128, 128}, {128, 128}, {128, 64},  {64, 64},   {128, 128}, {128, 64},  {64, 64}};
+constexpr int kMaxTile = 16;
+constexpr TileDims kTiles[kMaxTile + 1] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128}, {256, 256}, {256, 128}, {256, 128},
+                                          {256, 128}, {128, 128}, {128, 128}, {128, 64},  {64, 64},   {128, 128}, {128, 64},  {64, 64},
+                                          {256, 256}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -846,7 +781,7 @@ extern "C" int vneti_gemm_select_split(int M, int N, int K, int batch, int tile_
   if (batch <= 0) batch = 1;
   int cfg = tile_hint >= 100 ? tile_hint - 100 : tile_hint;
   if (cfg == 0) cfg = select_tile(M, N, batch);
-  if (cfg < 1 || cfg > 15 || K % 64 != 0) return -1;
+  if (cfg < 1 || cfg > kMaxTile || K % 64 != 0) return -1;
   int ks = select_ksplit(M, N, K, batch, cfg, workspace_bytes / 4);
   const int nk = K / 64;
   if (ks > nk) ks = nk;
@@ -969,8 +904,11 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     cfg -= 100;
   }
   if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
-  VN_REQUIRE(cfg >= 1 && cfg <= 15, "gemm: unknown tile_hint %d", d->tile_hint);
-  if (cfg == 5 && f32) cfg = 4;  // the 256x256 tile's f32 epilogue staging would not fit in LDS
+  VN_REQUIRE(cfg >= 1 && cfg <= kMaxTile, "gemm: unknown tile_hint %d", d->tile_hint);
+  // the 8-phase tile: LDS-DMA only; convolutions whose gather offset is linear in the tap (no fused upsample, no
+  // stride-2 transposed gather), tap-major K order
+  if (cfg == 16 && (!dma || (d->conv_mode && (d->conv_korder || d->ups || (d->conv_mode == 2 && d->stride == 2))))) cfg = 5;
+  if ((cfg == 5 || cfg == 16) && f32) cfg = 4;  // the 256x256 tiles' f32 epilogue staging would not fit in LDS
   if ((cfg == 6 || cfg == 7) && !dma) cfg = 4;  // the 3-stage ring exists with LDS-DMA only
   if (cfg >= 10 && !dma) cfg = kTiles[cfg].bm == 128 ? (kTiles[cfg].bn == 128 ? 1 : 2) : 3;
   long long ws_floats = d->workspace ? d->workspace_bytes / 4 : 0;
@@ -1009,6 +947,12 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     case 13: return launch_cfg_ring<128, 128, 64, 32, 4>(g, f32, st);
     case 14: return launch_cfg_ring<128, 64, 64, 32, 4>(g, f32, st);
     case 15: return launch_cfg_ring<64, 64, 32, 32, 4>(g, f32, st);
+    case 16: {  // 256x256 as 8 waves in the 8-phase ping-pong structure (gemm8.hip)
+      const int rc = vneti_launch_gemm8(&g, st);
+      if (rc != VNETI_OK) return rc;
+      launch_reduce(g, st);
+      return vneti_check_launch("gemm8_kernel");
+    }
     default:
       return dma ? launch_cfg_f16<256, 256, 64, 64, true>(g, st) : launch_cfg_f16<256, 256, 64, 64, false>(g, st);
   }
