@@ -108,6 +108,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   // (Fused upsampling and the stride-2 transposed gather are not linear in the tap: those launches stay on tile 5.)
   const int lrow = tid >> 3;
   const int gchunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  const float rcp_hw = CONV ? 1.0f / (float)(g.Ho * g.Wo) : 0.f, rcp_wo = CONV ? 1.0f / (float)g.Wo : 0.f;
   int a_base[4];
   uint32_t a_mask[4];
 #pragma unroll
@@ -118,21 +119,25 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       a_base[r] = (int)((long long)m * g.lda * 2) + gchunk * 16;
       a_mask[r] = ok ? 1u : 0u;
     } else {
+      // (b, oy, ox) of output pixel m without integer division: m < 2^24 (checked by the launcher), so the float
+      // quotient is off by at most one
       const int hw = g.Ho * g.Wo;
-      const int b = m / hw;
-      const int rem = m - b * hw;
-      const int oy = rem / g.Wo;
-      const int ox = rem - oy * g.Wo;
+      int b = (int)((float)m * rcp_hw);
+      int rem = m - b * hw;
+      if (rem < 0) { b -= 1; rem += hw; } else if (rem >= hw) { b += 1; rem -= hw; }
+      int oy = (int)((float)rem * rcp_wo);
+      int ox = rem - oy * g.Wo;
+      if (ox < 0) { oy -= 1; ox += g.Wo; } else if (ox >= g.Wo) { oy += 1; ox -= g.Wo; }
       const int py = e_conv == 1 ? oy * g.stride - g.pad_t : oy + g.pad_t;
       const int px = e_conv == 1 ? ox * g.stride - g.pad_l : ox + g.pad_l;
       a_base[r] = ((b * g.Hi + py) * g.Wi + px) * g.ldx2 + gchunk * 16;
-      uint32_t mask = 0;
+      // tap (dy, dx) reads input pixel (py +- dy, px +- dx): three row bits x three column bits
+      const int sgn = e_conv == 1 ? 1 : -1;
+      uint32_t colbits = 0, mask = 0;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap - 3 * (tap / 3);
-        const int iy = e_conv == 1 ? py + dy : py - dy, ix = e_conv == 1 ? px + dx : px - dx;
-        if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) mask |= 1u << tap;
-      }
+      for (int d = 0; d < 3; ++d) colbits |= ((unsigned)(px + sgn * d) < (unsigned)g.Wi ? 1u : 0u) << d;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) mask |= ((unsigned)(py + sgn * d) < (unsigned)g.Hi ? colbits : 0u) << (3 * d);
       a_mask[r] = ok ? mask : 0u;
     }
   }
@@ -240,6 +245,17 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         bf1[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdB[s] + HALF_BYTES + jb * 2048));
   };
 
+  // the bias of this lane's 16 columns, requested before the main loop (its L2 round trip would otherwise sit between
+  // the last MFMA and the first C-tile write); out-of-range columns and a null bias read as zeros
+  f32x4 bv[2][2];
+  {
+    const __amdgpu_buffer_rsrc_t rsBias = vn_make_rsrc(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+        bv[j][jb] = __builtin_bit_cast(f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + j * 128 + wc * 32 + jb * 16 + 4 * fq) * 4u));
+  }
   f32x4 acc[2][2][4][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -372,14 +388,11 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     for (int i = tid; i < GN_IMG * GN_NG * 2; i += NT) gacc[i] = 0.f;
   }
   // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ----
+  // Rows are 528 B apart (132 dwords = 4 mod 32 banks), so the 16 rows a ds_write_b64 lane group covers would hit every
+  // bank pair twice; rows with bit 3 set therefore store the two 8-byte halves of each 16-byte chunk swapped (bank + 2),
+  // which phase 2 undoes in registers (there the rows of a thread all share that bit: it is wave-uniform).
   {
-    const __amdgpu_buffer_rsrc_t rsBias = vn_make_rsrc(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
-    f32x4 bv[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-        bv[j][jb] = __builtin_bit_cast(f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + j * 128 + wc * 32 + jb * 16 + 4 * fq) * 4u));
+    const int nsw = ((frow >> 3) & 1) << 2;  // element offset of the half swap
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
           for (int jb = 0; jb < 2; ++jb) {
             const int ml = h * 128 + wr * 64 + i * 16 + frow;
-            const int nl = j * 128 + wc * 32 + jb * 16 + 4 * fq;
+            const int nl = (j * 128 + wc * 32 + jb * 16 + 4 * fq) ^ nsw;
             half4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (half_t)apply_act(acc[h][j][i][jb][e] * g.alpha + bv[j][jb][e], e_act);
@@ -399,20 +412,28 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   __syncthreads();
   VN_STAMP(3);
 
-  // ---- epilogue phase 2: coalesced row-major stores with the fused operands (same code as gemm_conv.hip's f16 path) ----
+  // ---- epilogue phase 2: coalesced row-major stores with the fused operands.  A thread owns one 8-column chunk
+  // (column c = 8 * (tid % 32)) of rows tid / 32 + 16 * it, it = 0..15, handled U rows at a time: the C chunks (LDS) and
+  // every fused operand (residual, row-add, gate: buffer loads, out-of-range => zeros) of a batch are requested before
+  // any of them is used, so a tile pays 16 / U memory round trips instead of 16 serialised ones. ----
   half_t* Cb = reinterpret_cast<half_t*>(g.C) + (long long)bz * g.strideC;
   const half_t* Rb = reinterpret_cast<const half_t*>(g.resid);
   if (Rb) Rb += (long long)bz * g.strideC;
   constexpr int CPR = BN / 8;
+  constexpr int U = EPI == 2 ? 2 : (EPI == 1 ? 4 : 8);
   static_assert(NT % CPR == 0 && CPR <= 32 && (BM * CPR) % NT == 0, "a thread keeps one 8-column chunk over all its rows");
   float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
   const bool gn = e_gn_sums != nullptr;
+  const float rcp_gnhw = gn ? 1.0f / (float)g.gn_hw : 0.f, rcp_rpg = e_rowadd ? 1.0f / (float)g.rows_per_group : 0.f;
   const int gn_img0 = gn ? m0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
-  const int gn_c = n0 + (tid % CPR) * 8;
-  const int gn_glo = gn ? gn_c / g.gn_cpg : 0;
-  const int gn_split = gn ? (gn_glo + 1) * g.gn_cpg - gn_c : 8;  // columns [0, split) of the chunk are in group lo
+  const int c = (tid % CPR) * 8;
+  const int n = n0 + c;
+  const int gn_glo = gn ? n / g.gn_cpg : 0;
+  const int gn_split = gn ? (gn_glo + 1) * g.gn_cpg - n : 8;  // columns [0, split) of the chunk are in group lo
   int gn_img = -1;
   float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
+  // flush = wave-uniform: the lanes that share a chunk column (lane % CPR) are summed with cross-lane moves first, so a
+  // wave issues CPR x 4 LDS atomics on mostly distinct addresses instead of 256 colliding ones
   auto gn_flush = [&]() {
     const int iref = __builtin_amdgcn_readfirstlane(gn_img);
     const bool uni = __all(gn_img == iref) && iref >= 0;
@@ -436,98 +457,133 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     }
     s_lo = q_lo = s_hi = q_hi = 0.f;
   };
-  for (int idx = tid; idx < BM * CPR; idx += NT) {  // BM * CPR is a multiple of NT: uniform trip count
-    const int r = idx / CPR, c = (idx - r * CPR) * 8;
-    const int m = m0 + r, n = n0 + c;
-    const bool valid = m < g.M && n < g.N;
-    if (gn) {
-      const int img = valid ? m / g.gn_hw : gn_img;
-      if (__any(img != gn_img)) {
-        gn_flush();
-        gn_img = img;
+  const bool full_chunk = n + 8 <= g.N;  // false only in the last column chunk of an N that is no multiple of 8
+  const bool swap_halves = (tid >> 8) & 1;  // rows tid / 32 + 16 * it have bit 3 set for waves 4..7 (see phase 1)
+  const __amdgpu_buffer_rsrc_t rsR = vn_make_rsrc(Rb, Rb ? 0x7fffffffu : 0u);
+  const __amdgpu_buffer_rsrc_t rsRA = vn_make_rsrc(e_rowadd, e_rowadd ? 0x7fffffffu : 0u);
+  const __amdgpu_buffer_rsrc_t rsG = vn_make_rsrc(e_gate, e_gate ? 0x7fffffffu : 0u);
+  const int r_first = tid / CPR;
+  for (int it0 = 0; it0 < BM / 16; it0 += U) {
+    half8 cv[U], rv[U], av[U], gv[U], gv2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r_first + 16 * (it0 + u);
+      const int m = m0 + r;
+      const bool ok = m < g.M && full_chunk;
+      u32x4 t = *reinterpret_cast<const u32x4*>(smem + ((size_t)r * CS_LD + c) * 2);
+      if (swap_halves) t = u32x4{t[2], t[3], t[0], t[1]};
+      cv[u] = as_half8(t);
+      if (Rb) rv[u] = as_half8(vn_buf_load16(rsR, ok ? (uint32_t)(((long long)m * g.ldr + n) * 2) : VN_OOB));
+      if (EPI >= 1) {
+        int grp = 0;
+        if (e_rowadd) {
+          grp = (int)((float)m * rcp_rpg);  // m / rows_per_group, m < 2^24: the float quotient is off by at most one
+          const int rem = m - grp * g.rows_per_group;
+          grp += rem >= g.rows_per_group ? 1 : (rem < 0 ? -1 : 0);
+        }
+        if (e_rowadd) av[u] = as_half8(vn_buf_load16(rsRA, ok ? (uint32_t)(((long long)grp * g.ld_rowadd + n) * 2) : VN_OOB));
+      }
+      if (EPI == 2 && e_gate) {
+        const long long go = (long long)m * g.ld_gate + (e_geglu == 2 ? 2 * n : n);
+        gv[u] = as_half8(vn_buf_load16(rsG, ok ? (uint32_t)(go * 2) : VN_OOB));
+        gv2[u] = as_half8(vn_buf_load16(rsG, (ok && e_geglu == 2) ? (uint32_t)(go * 2 + 16) : VN_OOB));
       }
     }
-    if (!valid) continue;
-    half8 v = as_half8(*reinterpret_cast<const u32x4*>(smem + ((size_t)r * CS_LD + c) * 2));
-    const half_t* radd = e_rowadd ? e_rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + n : nullptr;
-    if (n + 8 <= g.N) {
-      if (radd) {
-        const half8 t = *reinterpret_cast<const half8*>(radd);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)t[e]);
-      }
-      if (Rb) {
-        const half8 rr = *reinterpret_cast<const half8*>(Rb + (long long)m * g.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
-      }
-      if (e_geglu == 2) {
-        // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]
-        const half_t* pp = e_gate + (long long)m * g.ld_gate + 2 * n;
-        half_t* dp = Cb + (long long)m * g.ldc + 2 * n;
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-          const half8 pre = *reinterpret_cast<const half8*>(pp + 8 * c2);
-          half8 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float d = (float)v[4 * c2 + e], hh = (float)pre[e], gg = (float)pre[4 + e];
-            float cdf, xpdf;
-            vn_gelu_parts(gg, cdf, xpdf);
-            o[e] = (half_t)(d * gg * cdf);
-            o[4 + e] = (half_t)(d * hh * (cdf + xpdf));
-          }
-          *reinterpret_cast<half8*>(dp + 8 * c2) = o;
-        }
-        continue;
-      }
-      if (e_gate) {
-        const half8 pre = *reinterpret_cast<const half8*>(e_gate + (long long)m * g.ld_gate + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)pre[e], g.gate_act));
-      }
-      *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
-      if (e_geglu == 1) {
-        half4 o2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o2[e] = (half_t)((float)v[e] * vn_gelu_erf((float)v[4 + e]));
-        *reinterpret_cast<half4*>(e_C2 + (long long)m * g.ldc2 + (n >> 1)) = o2;
-      }
+    for (int u = 0; u < U; ++u) {
+      const int r = r_first + 16 * (it0 + u);
+      const int m = m0 + r;
+      const bool valid = m < g.M && n < g.N;
       if (gn) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = (float)v[e];
-          if (e < gn_split) {
-            s_lo += x;
-            q_lo += x * x;
-          } else {
-            s_hi += x;
-            q_hi += x * x;
-          }
+        int img = gn_img;
+        if (valid) {
+          img = (int)((float)m * rcp_gnhw);
+          const int rem = m - img * g.gn_hw;
+          img += rem >= g.gn_hw ? 1 : (rem < 0 ? -1 : 0);
+        }
+        if (__any(img != gn_img)) {
+          gn_flush();
+          gn_img = img;
         }
       }
-      if (e_C2 && e_geglu == 0) {
-        half8 o2;
+      if (!valid) continue;
+      half8 v = cv[u];
+      if (full_chunk) {
+        if (EPI >= 1 && e_rowadd) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o2[e] = (half_t)apply_act((float)v[e], g.act2);
-        *reinterpret_cast<half8*>(e_C2 + (long long)m * g.ldc2 + n) = o2;
-      }
-    } else {
-      for (int e = 0; e < 8 && n + e < g.N; ++e) {
-        float x = (float)v[e];
-        if (radd) x = (float)(half_t)(x + (float)radd[e]);
-        if (Rb) x = (float)(half_t)(x + (float)Rb[(long long)m * g.ldr + n + e]);
-        if (e_gate) x = (float)(half_t)(x * act_grad((float)e_gate[(long long)m * g.ld_gate + n + e], g.gate_act));
-        Cb[(long long)m * g.ldc + n + e] = (half_t)x;
-        if (e_C2) e_C2[(long long)m * g.ldc2 + n + e] = (half_t)apply_act((float)(half_t)x, g.act2);
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)av[u][e]);
+        }
+        if (Rb) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[u][e]);
+        }
+        if (e_geglu == 2) {
+          // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]
+          half_t* dp = Cb + (long long)m * g.ldc + 2 * n;
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const half8 pre = c2 == 0 ? gv[u] : gv2[u];
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = (float)v[4 * c2 + e], hh = (float)pre[e], gg = (float)pre[4 + e];
+              float cdf, xpdf;
+              vn_gelu_parts(gg, cdf, xpdf);
+              o[e] = (half_t)(d * gg * cdf);
+              o[4 + e] = (half_t)(d * hh * (cdf + xpdf));
+            }
+            *reinterpret_cast<half8*>(dp + 8 * c2) = o;
+          }
+          continue;
+        }
+        if (e_gate) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)gv[u][e], g.gate_act));
+        }
+        *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
+        if (e_geglu == 1) {
+          half4 o2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o2[e] = (half_t)((float)v[e] * vn_gelu_erf((float)v[4 + e]));
+          *reinterpret_cast<half4*>(e_C2 + (long long)m * g.ldc2 + (n >> 1)) = o2;
+        }
         if (gn) {
-          const float xs = (float)(half_t)x;
-          if (e < gn_split) {
-            s_lo += xs;
-            q_lo += xs * xs;
-          } else {
-            s_hi += xs;
-            q_hi += xs * xs;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = (float)v[e];
+            if (e < gn_split) {
+              s_lo += x;
+              q_lo += x * x;
+            } else {
+              s_hi += x;
+              q_hi += x * x;
+            }
+          }
+        }
+        if (e_C2 && e_geglu == 0) {
+          half8 o2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o2[e] = (half_t)apply_act((float)v[e], g.act2);
+          *reinterpret_cast<half8*>(e_C2 + (long long)m * g.ldc2 + n) = o2;
+        }
+      } else {  // ragged last chunk (N % 8 != 0): element-wise, operands straight from memory
+        const half_t* radd = e_rowadd ? e_rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + n : nullptr;
+        for (int e = 0; e < 8 && n + e < g.N; ++e) {
+          float x = (float)v[e];
+          if (radd) x = (float)(half_t)(x + (float)radd[e]);
+          if (Rb) x = (float)(half_t)(x + (float)Rb[(long long)m * g.ldr + n + e]);
+          if (e_gate) x = (float)(half_t)(x * act_grad((float)e_gate[(long long)m * g.ld_gate + n + e], g.gate_act));
+          Cb[(long long)m * g.ldc + n + e] = (half_t)x;
+          if (e_C2) e_C2[(long long)m * g.ldc2 + n + e] = (half_t)apply_act((float)(half_t)x, g.act2);
+          if (gn) {
+            const float xs = (float)(half_t)x;
+            if (e < gn_split) {
+              s_lo += xs;
+              q_lo += xs * xs;
+            } else {
+              s_hi += xs;
+              q_hi += xs * xs;
+            }
           }
         }
       }
@@ -564,7 +620,9 @@ inline int epilogue_level8(const GemmArgs& g) {
 // split-K reduce itself.  Returns VNETI_EUNSUP for what this tile does not carry (f32 output, chunk-major conv K order).
 int vneti_launch_gemm8(void* gemm_args, hipStream_t st) {
   GemmArgs& g = *reinterpret_cast<GemmArgs*>(gemm_args);
-  if (g.out_f32 || (g.conv_mode && (g.korder || g.ups || (g.conv_mode == 2 && g.stride == 2)))) return VNETI_EUNSUP;
+  if (g.out_f32 || (g.conv_mode && (g.korder || g.ups || (g.conv_mode == 2 && g.stride == 2))) ||
+      (g.M >= (1 << 24) && (g.conv_mode || g.rowadd || g.gn_sums)))  // float-reciprocal row arithmetic: rows < 2^24
+    return VNETI_EUNSUP;
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, BN);
   const dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit), block(NT);
