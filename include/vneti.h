@@ -94,10 +94,12 @@ typedef struct vneti_gemm_desc {
   int act2;
   /* GroupNorm statistics of the f16 output fused into the epilogue (split_k must be 1): the rows are images
      of gn_hw pixels, the N columns gn_groups groups of gn_cpg channels; every tile adds its (sum, sum of
-     squares) per (image, group) to gn_sums[image][tile_m % gn_slots][group][2] with atomics.  The caller
+     squares) per (image, group) to gn_sums[image][tile_m % gn_slots][group][4] — 64-bit fixed-point words
+     (sum.hi, sum.lo, sumsq.hi, sumsq.lo; csrc/common.h vn_fx_encode / vn_fx_decode) added with INTEGER atomics, so the
+     totals are bit-identical from run to run whatever order the tiles finish in.  The caller
      zeroes gn_sums; vneti_groupnorm_fwd_sums consumes it (the statistics pass of ResnetBlock2D.norm2 etc.
      without re-reading the tensor). */
-  float* gn_sums;
+  void* gn_sums;
   int gn_hw, gn_cpg, gn_groups, gn_slots;
   /* GEGLU (diffusers FeedForward: h, g = proj(x).chunk(2); h * gelu(g)) fused into the epilogue (f16 output, no
      split-K, N % 8 == 0).  The projection's output columns are INTERLEAVED in groups of four, [h0..h3 g0..g3 h4..h7
@@ -134,7 +136,7 @@ int vneti_im2col3x3_small(const void* x, int x_is_f32, long long sb, long long s
  * squares) of the stored values, layout and meaning as vneti_gemm_desc.gn_sums with gn_hw = H * W. */
 int vneti_conv3x3_in(const void* x, int x_is_f32, long long sb, long long sc, long long sy, long long sx,
                      const void* w_packed, const float* bias, void* out, long long ldo, int Bn, int C, int H, int W,
-                     int Co, float* gn_sums, int gn_groups, int gn_slots, void* stream);
+                     int Co, void* gn_sums, int gn_groups, int gn_slots, void* stream);
 
 /* batched 2-D transpose of f16 matrices: out[b][c][r] = in[b][r][c]; columns of `out` in
  * [rows, ld_out) are zero filled (attention kernels read K^T / V^T / Q^T / dO^T tiles). */
@@ -167,18 +169,18 @@ int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long long ldy, co
    (vneti_gemm_desc.gn_sums, `slots` slots per sample): one launch that finishes mean / rstd from the sums,
    normalises, and publishes mean / rstd for the backward. */
 int vneti_groupnorm_fwd_sums(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
-                             const float* beta, const float* sums, int slots, float* mean, float* rstd,
+                             const float* beta, const void* sums, int slots, float* mean, float* rstd,
                              int Bn, int HW, int C, int G, float eps, int silu, void* stream);
 /* The same forward / backward in TWO launches for tensors beyond the one-block-per-group kernel: the statistics pass adds
-   its slab sums to `sums` ([Bn][slots][G][2] floats, zeroed by the caller before the launch, layout of
+   its slab sums to `sums` ([Bn][slots][G][4] 64-bit words, zeroed by the caller before the launch, layout of
    vneti_gemm_desc.gn_sums) and the apply kernel finishes them itself (no finalize launch).  Small tensors run the
    one-launch kernel of vneti_groupnorm_fwd / _bwd and leave `sums` alone (`ws` of the backward is only used there). */
 int vneti_groupnorm_fwd_2l(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
-                           const float* beta, float* sums, int slots, float* mean, float* rstd, int Bn, int HW,
+                           const float* beta, void* sums, int slots, float* mean, float* rstd, int Bn, int HW,
                            int C, int G, float eps, int silu, void* stream);
 int vneti_groupnorm_bwd_2l(const void* dy, long long lddy, const void* x, long long ldx, const float* gamma,
                            const float* beta, const float* mean, const float* rstd, void* dx, long long lddx,
-                           const void* dx_accum, long long ldacc, float* sums, int slots, float* ws, int Bn,
+                           const void* dx_accum, long long ldacc, void* sums, int slots, float* ws, int Bn,
                            int HW, int C, int G, int silu, void* stream);
 /* dx = d(loss)/d(x) given dy = d(loss)/d(y); y = silu?(GN(x)).  If dx_accum != NULL it is
  * added (f16, row stride lddx) — used where two gradient paths meet. */
@@ -280,6 +282,16 @@ int vneti_sample_add_noise(const void* moments, long long ldm, const float* eps,
                            const float* alphas_cumprod, float scaling, int v_prediction,
                            float* latents, float* noisy, float* target, int Bn, int Lc, int HW,
                            void* stream);
+/* The same three steps as separate entry points (identical arithmetic), for callers that keep the reference's
+ * module-call order: `vae.encode(x).latent_dist.sample()` (training/coach.py:165-169; scaling = 1 leaves the
+ * multiplication by vae.config.scaling_factor to the caller) ... */
+int vneti_latent_sample(const void* moments, long long ldm, const float* eps, float scaling, float* latents, int Bn,
+                        int Lc, int HW, void* stream);
+/* ... and `noise_scheduler.add_noise(latents, noise, timesteps)` / `.get_velocity(...)` (training/coach.py:182-183,
+ * 201-205): noisy and target are NCHW f32 like the inputs; either may be null; target = noise (epsilon) or the
+ * velocity (v_prediction). */
+int vneti_add_noise(const float* latents, const float* noise, const void* timesteps_i64, const float* alphas_cumprod,
+                    int v_prediction, float* noisy, float* target, int Bn, int Lc, int HW, void* stream);
 /* Inference (sd_pipeline_call.py:72-103): classifier-free guidance on the CFG-batched UNet output (rows
  * [0,B*HW) unconditional, [B*HW,2B*HW) conditional) and one sampler step in data-prediction form
  *   e = u + g (c - u);  x0 = (x - sigma_t e)/alpha_t  (epsilon)  |  alpha_t x - sigma_t e  (v_prediction)

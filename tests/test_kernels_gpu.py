@@ -219,14 +219,14 @@ def test_gemm_groupnorm_sums_and_fused_apply(hint, Bn, HW, C):
     bias = rnd(C, seed=63, dtype=torch.float32) * 2
     res = rnd(M, C, seed=64)
     out = torch.zeros(M, C + 8, dtype=torch.float16, device=DEV)[:, :C]
-    sums = torch.zeros(Bn, S, G, 2, dtype=torch.float32, device=DEV)
+    sums = torch.zeros(Bn, S, G, 4, dtype=torch.int64, device=DEV)  # fixed-point slot sums (csrc/common.h vn_fx_*)
     ops.gemm(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), tile_hint=hint, split_k=1,
              gn_sums=sums, gn_hw=HW, gn_groups=G, gn_slots=S)
     torch.cuda.synchronize()
     x = out.float().cpu().reshape(Bn, HW, G, C // G)
     ref_s = x.sum((1, 3))
     ref_q = (x * x).sum((1, 3))
-    got = sums.cpu().sum(1)
+    got = ops.gn_sums_decode(sums.sum(1))
     check(f"gn sums hint{hint}", got[..., 0], ref_s, 1e-3)
     check(f"gn sumsq hint{hint}", got[..., 1], ref_q, 1e-5)
     gamma = rnd(C, seed=65, dtype=torch.float32) * 0.1 + 1
@@ -340,7 +340,7 @@ def test_conv3x3_in_direct(Ci, Co, H, W, f32, gn):
     w = rnd(Co, Ci, 3, 3, scale=0.3, seed=22)
     bias = rnd(Co, seed=23, dtype=torch.float32)
     out = torch.zeros(Bn * H * W, Co + 8, dtype=torch.float16, device=DEV)[:, :Co]
-    sums = torch.zeros(Bn, S, G, 2, dtype=torch.float32, device=DEV) if gn else None
+    sums = torch.zeros(Bn, S, G, 4, dtype=torch.int64, device=DEV) if gn else None
     ops.conv3x3_in(xd, packing.conv_in_direct(w).to(DEV), bias.to(DEV), out, Bn, Ci, H, W, xd.stride(),
                    gn_sums=sums, gn_hw=H * W if gn else 0, gn_groups=G if gn else 0, gn_slots=S if gn else 0)
     torch.cuda.synchronize()
@@ -349,7 +349,7 @@ def test_conv3x3_in_direct(Ci, Co, H, W, f32, gn):
     check(f"conv_in direct C{Ci} Co{Co}", out.reshape(Bn, H, W, Co), _nhwc(ref), 2e-3)
     if gn:
         xo = out.float().cpu().reshape(Bn, H * W, G, Co // G)
-        got = sums.cpu().sum(1)
+        got = ops.gn_sums_decode(sums.sum(1))
         check("conv_in gn sums", got[..., 0], xo.sum((1, 3)), 1e-3)
         check("conv_in gn sumsq", got[..., 1], (xo * xo).sum((1, 3)), 1e-5)
 
@@ -394,8 +394,8 @@ def test_groupnorm_fwd_bwd(Cc, HW, silu, three_launch, monkeypatch):
     S = 8
     y2, dx2 = torch.zeros_like(xd), torch.zeros_like(xd)
     mean2, rstd2 = torch.zeros_like(mean), torch.zeros_like(mean)
-    fs = torch.zeros(Bn, S, G, 2, dtype=torch.float32, device=DEV)
-    bs = torch.zeros(Bn, S, G, 2, dtype=torch.float32, device=DEV)
+    fs = torch.zeros(Bn, S, G, 4, dtype=torch.int64, device=DEV)
+    bs = torch.zeros(Bn, S, G, 4, dtype=torch.int64, device=DEV)
     ops.groupnorm_fwd_2l(xd, y2, gamma.to(DEV), beta.to(DEV), fs, S, mean2, rstd2, Bn, HW, Cc, G, eps, silu)
     ops.groupnorm_bwd_2l(dy.to(DEV).view(Bn * HW, Cc), xd, gamma.to(DEV), beta.to(DEV), mean2, rstd2, dx2, bs, S, ws, Bn,
                          HW, Cc, G, silu, accum=acc)

@@ -118,6 +118,37 @@ def test_graph_replay_equals_eager_and_trains():
     assert eng.opt_step.item() == 6  # capture() must not leave a warm-up update behind
 
 
+@pytest.mark.parametrize("cfg_name,B,H,W", [("tiny", 2, 64, 64), ("sd15", 1, 512, 512)], ids=["tiny", "sd15-512"])
+def test_two_runs_are_bit_identical(cfg_name, B, H, W):
+    """Every reduction of the step is order-independent (GroupNorm statistics: fixed-point integer atomics,
+    csrc/common.h vn_fx_*; everything else: fixed-order trees), so the same inputs give the same bits — gradients, the
+    prediction, and the parameters after optimizer steps — from one run to the next."""
+    from view_neti_amd import synth
+    cfg, eng, _, _, _, _ = build(cfg_name, B, H, W, device_rng=False, lr=1e-3)
+    ph = cfg.clip.vocab_size - 3
+    eng.set_batch(synth.pixel_values(B, H, W), synth.input_ids(B, ph, cfg.clip.vocab_size), torch.full((B,), ph))
+    eng.set_noise(synth.gaussian((B, 4, H // 8, W // 8), 3), synth.gaussian((B, 4, H // 8, W // 8), 4), synth.timesteps(B))
+    runs = []
+    for _ in range(3):
+        eng.forward_backward()
+        torch.cuda.synchronize()
+        runs.append((eng.grads.clone(), eng.unet.pred.clone(), eng.latents.clone(), eng.unet.dctx_k.clone()))
+    for r in runs[1:]:
+        for a, b, what in zip(runs[0], r, ("mapper gradients", "prediction", "latents", "context gradients")):
+            assert torch.equal(a, b), f"{what} differ between two identical runs"
+    if cfg_name == "tiny":  # and across engines / graph replays: two fresh engines, four optimizer steps each
+        outs = []
+        for _ in range(2):
+            _, e2, _, _, _, _ = build(cfg_name, B, H, W, device_rng=True, lr=1e-3, seed=9)
+            e2.set_batch(synth.pixel_values(B, H, W), synth.input_ids(B, ph, cfg.clip.vocab_size), torch.full((B,), ph))
+            e2.capture()
+            for _ in range(4):
+                e2.step()
+            torch.cuda.synchronize()
+            outs.append((e2.params.clone(), e2.exp_avg_sq.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_multi_object_mappers_and_segmented_adamw():
     """learnable_mode 3 (BASELINE config 4): several object mappers + one view mapper in one bucket; the
     batch's scene picks the object mapper on the device (graph replay safe); AdamW keeps torch's

@@ -81,6 +81,37 @@ __device__ __forceinline__ float vn_gelu_erf_grad(float x) {
   return cdf + xpdf;
 }
 
+// ---- order-independent accumulation of float partial sums (the GroupNorm statistics) -------------------------------
+// Float atomics make a sum depend on arrival order; integers do not.  A partial sum v is added as two 64-bit integers:
+//   hi = rint(v * 2^4)                      (coarse, never overflows: |v| < 2^58)
+//   lo = rint(v * 2^40)  modulo 2^64        (fine; wraps for |total| >= 2^23, which the decoder undoes from hi)
+// so every run — any block order, any atomic order — produces bit-identical totals with 2^-40 absolute resolution over the
+// whole float range.  One accumulated quantity = 2 words; a GroupNorm slot entry = [S1.hi, S1.lo, S2.hi, S2.lo].
+typedef unsigned long long vn_u64;
+__device__ __forceinline__ void vn_fx_encode(float v, vn_u64& hi, vn_u64& lo) {
+  const float vh = rintf(v * 16.f);
+  const long long h = (long long)vh;
+  const float rem = v - vh * 0.0625f;  // exact: |rem| <= 2^-5, and 0 once |v| >= 2^19
+  hi = (vn_u64)h;
+  lo = ((vn_u64)h << 36) + (vn_u64)(long long)rintf(rem * 1099511627776.f);
+}
+__device__ __forceinline__ double vn_fx_decode(vn_u64 hi_u, vn_u64 lo_u) {
+  const long long hi = (long long)hi_u, lo = (long long)lo_u;
+  // total * 2^40 = lo + k * 2^64, k = the integer that brings it next to hi * 2^36
+  const double k = rint(((double)hi * 68719476736.0 - (double)lo) * 5.421010862427522e-20);
+  return (double)lo * 9.094947017729282e-13 + k * 16777216.0;
+}
+// add (s, q) to a 4-word entry with integer atomics (LDS or global)
+__device__ __forceinline__ void vn_fx_add2(vn_u64* e, float s, float q) {
+  vn_u64 h, l;
+  vn_fx_encode(s, h, l);
+  atomicAdd(e, h);
+  atomicAdd(e + 1, l);
+  vn_fx_encode(q, h, l);
+  atomicAdd(e + 2, h);
+  atomicAdd(e + 3, l);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -23,7 +23,7 @@ struct ConvInArgs {
   half_t* out;
   long long ldo;
   int Bn, C, H, W, Co;
-  float* gn_sums;
+  void* gn_sums;  // 64-bit fixed-point slot sums, see common.h
   int gn_cpg, gn_G, gn_slots;
 };
 
@@ -31,13 +31,13 @@ constexpr int PIX_PER_BLOCK = 256;  // 4 waves x 4 groups of 16 pixels
 
 template <bool F32IN>
 __global__ __launch_bounds__(256) void conv_in_kernel(ConvInArgs a) {
-  __shared__ float gacc[32 * 2];  // (sum, sumsq) of the 32 channel quads of this 128-channel block
+  __shared__ vn_u64 gacc[32 * 4];  // fixed-point (sum, sumsq) of the 32 channel quads of this 128-channel block (common.h)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fq = lane >> 4;
   const int nb = blockIdx.y;  // 128-channel block
   const long long HW = (long long)a.H * a.W;
   const bool gn = a.gn_sums != nullptr;
-  if (tid < 64) gacc[tid] = 0.f;
+  if (tid < 128) gacc[tid] = 0;
 
   // weights of this channel block: 8 row blocks of 16 x 32 halfs, one 16-byte chunk per lane each
   half8 wf[8];
@@ -124,23 +124,21 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvInArgs a) {
       }
       if (frow == 0) {
         const int quad = (j >> 1) * 8 + fq * 2 + (j & 1);  // channel quad inside the 128-channel block
-        atomicAdd(&gacc[2 * quad], gs[j]);
-        atomicAdd(&gacc[2 * quad + 1], gq[j]);
+        vn_fx_add2(&gacc[4 * quad], gs[j], gq[j]);  // integer atomics: order-independent totals
       }
     }
     __syncthreads();
     const int qpg = a.gn_cpg >> 2;  // quads per group
     const int ng = 32 / qpg;        // groups in this channel block
     if (tid < ng) {
-      float sv = 0.f, qv = 0.f;
-      for (int i = 0; i < qpg; ++i) {
-        sv += gacc[2 * (tid * qpg + i)];
-        qv += gacc[2 * (tid * qpg + i) + 1];
-      }
+      vn_u64 t[4] = {0, 0, 0, 0};
+      for (int i = 0; i < qpg; ++i)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t[w] += gacc[4 * (tid * qpg + i) + w];
       const int img = (int)(m_blk / HW), slot = blockIdx.x % a.gn_slots, grp = nb * ng + tid;
-      float* dst = a.gn_sums + (((long long)img * a.gn_slots + slot) * a.gn_G + grp) * 2;
-      unsafeAtomicAdd(dst, sv);
-      unsafeAtomicAdd(dst + 1, qv);
+      vn_u64* dst = reinterpret_cast<vn_u64*>(a.gn_sums) + (((long long)img * a.gn_slots + slot) * a.gn_G + grp) * 4;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) atomicAdd(dst + w, t[w]);
     }
   }
 }
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvInArgs a) {
 
 extern "C" int vneti_conv3x3_in(const void* x, int x_is_f32, long long sb, long long sc, long long sy, long long sx,
                                 const void* w_packed, const float* bias, void* out, long long ldo, int Bn, int C, int H,
-                                int W, int Co, float* gn_sums, int gn_groups, int gn_slots, void* stream) {
+                                int W, int Co, void* gn_sums, int gn_groups, int gn_slots, void* stream) {
   VN_REQUIRE(x && w_packed && out, "conv3x3_in: null pointer");
   VN_REQUIRE(C >= 1 && C <= 3, "conv3x3_in: C=%d (9*C must fit one 32-wide k-step)", C);
   VN_REQUIRE(Co > 0 && Co % 128 == 0, "conv3x3_in: Co=%d must be a multiple of 128", Co);

@@ -192,6 +192,19 @@ __global__ void rng_advance_kernel(uint32_t* state) {
 //   latents = (mean + exp(0.5*clamp(logvar,-30,20))*eps) * scaling
 //   noisy   = sqrt(ac[t]) * latents + sqrt(1-ac[t]) * noise
 //   target  = noise (epsilon) or sqrt(ac)*noise - sqrt(1-ac)*latents (v_prediction)
+// (the three steps are device helpers so that the split entry points below — vneti_latent_sample / vneti_add_noise, the
+// module-call seam of compat/sd_modules.py — round exactly as the fused kernel does)
+__device__ __forceinline__ float vn_latent_sample(const half_t* m, int c, int Lc, float eps, float scaling) {
+  float mean = (float)m[c];
+  float logvar = fminf(fmaxf((float)m[Lc + c], -30.f), 20.f);
+  return fmaf(__expf(0.5f * logvar), eps, mean) * scaling;  // explicit fma: the same rounding in every kernel that inlines this
+}
+__device__ __forceinline__ void vn_add_noise(float z, float n, float a, int vpred, float& noisy, float& target) {
+  float sa = sqrtf(a), sb = sqrtf(1.f - a);
+  noisy = fmaf(sa, z, sb * n);
+  target = vpred ? fmaf(sa, n, -(sb * z)) : n;
+}
+
 __global__ void sample_add_noise_kernel(const half_t* moments, long long ldm, const float* eps,
                                         const float* noise, const long long* t, const float* ac, float scaling,
                                         int vpred, float* latents, float* noisy, float* target, int Bn, int Lc,
@@ -202,16 +215,35 @@ __global__ void sample_add_noise_kernel(const half_t* moments, long long ldm, co
   int p = gid % HW;
   int c = (gid / HW) % Lc;
   int b = gid / (HW * Lc);
-  const half_t* m = moments + ((long long)b * HW + p) * ldm;
-  float mean = (float)m[c];
-  float logvar = fminf(fmaxf((float)m[Lc + c], -30.f), 20.f);
-  float z = (mean + __expf(0.5f * logvar) * eps[gid]) * scaling;
-  float a = ac[t[b]];
-  float sa = sqrtf(a), sb = sqrtf(1.f - a);
-  float n = noise[gid];
+  float z = vn_latent_sample(moments + ((long long)b * HW + p) * ldm, c, Lc, eps[gid], scaling);
+  float ny, tg;
+  vn_add_noise(z, noise[gid], ac[t[b]], vpred, ny, tg);
   latents[gid] = z;
-  noisy[gid] = sa * z + sb * n;
-  target[gid] = vpred ? (sa * n - sb * z) : n;
+  noisy[gid] = ny;
+  target[gid] = tg;
+}
+
+// latent_dist.sample() (* scaling) alone: AutoencoderKL.encode(x).latent_dist.sample() of the module-call seam
+__global__ void latent_sample_kernel(const half_t* moments, long long ldm, const float* eps, float scaling,
+                                     float* latents, int Bn, int Lc, int HW) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= Bn * Lc * HW) return;
+  int p = gid % HW;
+  int c = (gid / HW) % Lc;
+  int b = gid / (HW * Lc);
+  latents[gid] = vn_latent_sample(moments + ((long long)b * HW + p) * ldm, c, Lc, eps[gid], scaling);
+}
+
+// DDPMScheduler.add_noise / get_velocity alone (noisy and / or target may be null)
+__global__ void add_noise_kernel(const float* latents, const float* noise, const long long* t, const float* ac, int vpred,
+                                 float* noisy, float* target, int Bn, int Lc, int HW) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= Bn * Lc * HW) return;
+  int b = gid / (HW * Lc);
+  float ny, tg;
+  vn_add_noise(latents[gid], noise[gid], ac[t[b]], vpred, ny, tg);
+  if (noisy) noisy[gid] = ny;
+  if (target) target[gid] = tg;
 }
 
 // ---- inference: classifier-free guidance + one sampler step (sd_pipeline_call.py:72-103) ---------------
@@ -518,6 +550,26 @@ extern "C" int vneti_sample_add_noise(const void* moments, long long ldm, const 
                      eps, noise, (const long long*)timesteps, alphas_cumprod, scaling, v_prediction, latents, noisy,
                      target, Bn, Lc, HW);
   return vneti_check_launch("sample_add_noise");
+}
+
+extern "C" int vneti_latent_sample(const void* moments, long long ldm, const float* eps, float scaling, float* latents,
+                                   int Bn, int Lc, int HW, void* stream) {
+  VN_REQUIRE(moments && eps && latents && Bn > 0 && Lc > 0 && HW > 0, "latent_sample: bad arguments");
+  int n = Bn * Lc * HW;
+  hipLaunchKernelGGL(latent_sample_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (const half_t*)moments, ldm, eps, scaling,
+                     latents, Bn, Lc, HW);
+  return vneti_check_launch("latent_sample");
+}
+
+extern "C" int vneti_add_noise(const float* latents, const float* noise, const void* timesteps_i64,
+                               const float* alphas_cumprod, int v_prediction, float* noisy, float* target, int Bn, int Lc,
+                               int HW, void* stream) {
+  VN_REQUIRE(latents && noise && timesteps_i64 && alphas_cumprod && (noisy || target) && Bn > 0 && Lc > 0 && HW > 0,
+             "add_noise: bad arguments");
+  int n = Bn * Lc * HW;
+  hipLaunchKernelGGL(add_noise_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, latents, noise,
+                     (const long long*)timesteps_i64, alphas_cumprod, v_prediction, noisy, target, Bn, Lc, HW);
+  return vneti_check_launch("add_noise");
 }
 
 extern "C" int vneti_cfg_sampler_step(const void* pred, long long ldp, float* x, float* m_prev, float* x_in, int Bn,

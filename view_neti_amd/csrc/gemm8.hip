@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   float* const e_gn_sums = EPI >= 1 ? g.gn_sums : nullptr;
   const half_t* const e_rowadd = EPI >= 1 ? g.rowadd : nullptr;
   const int e_conv = CONV ? g.conv_mode : 0;
-  constexpr int GN_BYTES = EPI == 0 ? 0 : GN_IMG * GN_NG * 2 * 4;
+  constexpr int GN_BYTES = EPI == 0 ? 0 : GN_IMG * GN_NG * 4 * 8;  // [image][group][S1.hi S1.lo S2.hi S2.lo] 64-bit words
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + GN_BYTES];
 
   const int tid = threadIdx.x;
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   }
 
   if (e_gn_sums) {
-    float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
-    for (int i = tid; i < GN_IMG * GN_NG * 2; i += NT) gacc[i] = 0.f;
+    vn_u64* gacc = reinterpret_cast<vn_u64*>(smem + LDS_BYTES);
+    for (int i = tid; i < GN_IMG * GN_NG * 4; i += NT) gacc[i] = 0;
   }
   // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ----
   // Rows are 528 B apart (132 dwords = 4 mod 32 banks), so the 16 rows a ds_write_b64 lane group covers would hit every
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   constexpr int CPR = BN / 8;
   constexpr int U = EPI == 2 ? 2 : (EPI == 1 ? 4 : 8);
   static_assert(NT % CPR == 0 && CPR <= 32 && (BM * CPR) % NT == 0, "a thread keeps one 8-column chunk over all its rows");
-  float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
+  vn_u64* gacc = reinterpret_cast<vn_u64*>(smem + LDS_BYTES);
   const bool gn = e_gn_sums != nullptr;
   const float rcp_gnhw = gn ? 1.0f / (float)g.gn_hw : 0.f, rcp_rpg = e_rowadd ? 1.0f / (float)g.rows_per_group : 0.f;
   const int gn_img0 = gn ? m0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
@@ -447,13 +447,10 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       }
     }
     if (gn_img >= 0 && (!uni || lane < CPR)) {
-      float* a = gacc + ((gn_img - gn_img0) * GN_NG + (gn_glo - gn_g0t)) * 2;
-      atomicAdd(a, s_lo);
-      atomicAdd(a + 1, q_lo);
-      if (gn_split < 8) {
-        atomicAdd(a + 2, s_hi);
-        atomicAdd(a + 3, q_hi);
-      }
+      // integer (fixed-point) atomics: the totals do not depend on the order the lanes / waves / blocks arrive in
+      vn_u64* a = gacc + ((gn_img - gn_img0) * GN_NG + (gn_glo - gn_g0t)) * 4;
+      vn_fx_add2(a, s_lo, q_lo);
+      if (gn_split < 8) vn_fx_add2(a + 4, s_hi, q_hi);
     }
     s_lo = q_lo = s_hi = q_hi = 0.f;
   };
@@ -594,12 +591,12 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     __syncthreads();
     const int slot = tile_m % g.gn_slots;
     for (int i = tid; i < GN_IMG * GN_NG; i += NT) {
-      const float sv = gacc[2 * i], qv = gacc[2 * i + 1];
-      if (sv == 0.f && qv == 0.f) continue;
+      const vn_u64* src = gacc + 4 * i;
+      if ((src[0] | src[1] | src[2] | src[3]) == 0) continue;
       const int img = gn_img0 + i / GN_NG, grp = gn_g0t + i % GN_NG;
-      float* dst = e_gn_sums + (((long long)img * g.gn_slots + slot) * g.gn_G + grp) * 2;
-      unsafeAtomicAdd(dst, sv);  // hardware global_atomic_add_f32
-      unsafeAtomicAdd(dst + 1, qv);
+      vn_u64* dst = reinterpret_cast<vn_u64*>(e_gn_sums) + (((long long)img * g.gn_slots + slot) * g.gn_G + grp) * 4;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) atomicAdd(dst + w, src[w]);
     }
   }
 #ifdef VN_GEMM8_STAMP

@@ -18,7 +18,7 @@ struct GemmArgs {
   half_t* C2;
   long long ld_gate, ldc2;
   int gate_act, act2;
-  float* gn_sums;  // [image][slot][G][2] running (sum, sum of squares) of the f16 output, see vneti_gemm_desc
+  float* gn_sums;  // [image][slot][G][4] 64-bit fixed-point (sum, sum of squares) of the f16 output (common.h vn_fx_*)
   int gn_hw, gn_cpg, gn_G, gn_slots;
   int geglu;  // 1: C2 = h * gelu(g) of the interleaved tile; 2: C[M][2N] = GEGLU backward against gate_src (see vneti.h)
   long long lda, ldb, ldc, ld_rowadd, ldr;

@@ -57,7 +57,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   constexpr int LDS_BYTES = (NSTG * STAGE_BYTES > CS_BYTES) ? NSTG * STAGE_BYTES : CS_BYTES;
   // GroupNorm statistics of the output tile (f16 epilogue only): [GN_IMG images][GN_NG groups][2] floats
   constexpr int GN_IMG = 5, GN_NG = BN / 4 + 2;
-  constexpr int GN_BYTES = (F32OUT || EPI == 0) ? 0 : GN_IMG * GN_NG * 2 * 4;
+  constexpr int GN_BYTES = (F32OUT || EPI == 0) ? 0 : GN_IMG * GN_NG * 4 * 8;  // [image][group][S1.hi S1.lo S2.hi S2.lo] 64-bit words
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + GN_BYTES];
 
   const int tid = threadIdx.x;
@@ -371,8 +371,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 
   if constexpr (!F32OUT) {
     if (e_gn_sums) {
-      float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
-      for (int i = tid; i < GN_IMG * GN_NG * 2; i += NT) gacc[i] = 0.f;
+      vn_u64* gacc = reinterpret_cast<vn_u64*>(smem + LDS_BYTES);
+      for (int i = tid; i < GN_IMG * GN_NG * 4; i += NT) gacc[i] = 0;
     }
   }
   // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ---------
@@ -442,7 +442,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     static_assert(NT % CPR == 0 && CPR <= 32 && (BM * CPR) % NT == 0, "a thread keeps one 8-column chunk over all its rows");
     // GroupNorm statistics of what this tile stores: a thread's chunk touches at most two groups (lo/hi, like
     // csrc/norms.hip); its running sums go to the LDS accumulators whenever the image changes and at the end
-    float* gacc = reinterpret_cast<float*>(smem + LDS_BYTES);
+    vn_u64* gacc = reinterpret_cast<vn_u64*>(smem + LDS_BYTES);
     const bool gn = e_gn_sums != nullptr;
     const int gn_img0 = gn ? m0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
     const int gn_c = n0 + (tid % CPR) * 8;
@@ -465,13 +465,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
         }
       }
       if (gn_img >= 0 && (!uni || lane < CPR)) {
-        float* a = gacc + ((gn_img - gn_img0) * GN_NG + (gn_glo - gn_g0t)) * 2;
-        atomicAdd(a, s_lo);
-        atomicAdd(a + 1, q_lo);
-        if (gn_split < 8) {
-          atomicAdd(a + 2, s_hi);
-          atomicAdd(a + 3, q_hi);
-        }
+        // integer (fixed-point) atomics: the totals do not depend on the order the lanes / waves / blocks arrive in
+        vn_u64* a = gacc + ((gn_img - gn_img0) * GN_NG + (gn_glo - gn_g0t)) * 4;
+        vn_fx_add2(a, s_lo, q_lo);
+        if (gn_split < 8) vn_fx_add2(a + 4, s_hi, q_hi);
       }
       s_lo = q_lo = s_hi = q_hi = 0.f;
     };
@@ -577,12 +574,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       __syncthreads();
       const int slot = tile_m % g.gn_slots;
       for (int i = tid; i < GN_IMG * GN_NG; i += NT) {
-        const float sv = gacc[2 * i], qv = gacc[2 * i + 1];
-        if (sv == 0.f && qv == 0.f) continue;
+        const vn_u64* src = gacc + 4 * i;
+        if ((src[0] | src[1] | src[2] | src[3]) == 0) continue;
         const int img = gn_img0 + i / GN_NG, grp = gn_g0t + i % GN_NG;
-        float* dst = e_gn_sums + (((long long)img * g.gn_slots + slot) * g.gn_G + grp) * 2;
-        unsafeAtomicAdd(dst, sv);  // hardware global_atomic_add_f32
-        unsafeAtomicAdd(dst + 1, qv);
+        vn_u64* dst = reinterpret_cast<vn_u64*>(e_gn_sums) + (((long long)img * g.gn_slots + slot) * g.gn_G + grp) * 4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) atomicAdd(dst + w, src[w]);
       }
     }
   }
@@ -810,7 +807,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   g.C2 = (half_t*)d->C2;
   g.ldc2 = d->ldc2;
   g.act2 = d->act2;
-  g.gn_sums = d->gn_sums;
+  g.gn_sums = (float*)d->gn_sums;  // 64-bit fixed-point words (common.h); the kernels reinterpret
   g.gn_hw = d->gn_hw;
   g.gn_cpg = d->gn_cpg;
   g.gn_G = d->gn_groups;

@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNGeom g, const half_t* _
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd,
                                                        float* __restrict__ part, int slots = 0) {
-  __shared__ float gacc[2 * 64 * 2];  // [G<=64][2]
+  __shared__ vn_u64 gacc[64 * 4];  // [G <= 64][S1.hi S1.lo S2.hi S2.lo]: fixed-point sums (common.h), order-independent
   const int slab = blockIdx.x, b = blockIdx.y;
-  for (int i = threadIdx.x; i < 2 * g.G; i += 256) gacc[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * g.G; i += 256) gacc[i] = 0;
   __syncthreads();
   int tx, ty;
   bool active;
@@ -113,21 +113,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNGeom g, const half_t* _
           }
         }
       }
-      atomicAdd(&gacc[2 * g0], a_lo);
-      atomicAdd(&gacc[2 * g0 + 1], b_lo);
-      if (split < 8) {
-        atomicAdd(&gacc[2 * (g0 + 1)], a_hi);
-        atomicAdd(&gacc[2 * (g0 + 1) + 1], b_hi);
-      }
+      vn_fx_add2(&gacc[4 * g0], a_lo, b_lo);
+      if (split < 8) vn_fx_add2(&gacc[4 * (g0 + 1)], a_hi, b_hi);
     }
   }
   __syncthreads();
   if constexpr (SLOTS) {
-    float* p = part + ((long long)b * slots + slab % slots) * (2 * g.G);
-    for (int i = threadIdx.x; i < 2 * g.G; i += 256) unsafeAtomicAdd(p + i, gacc[i]);
+    vn_u64* p = reinterpret_cast<vn_u64*>(part) + ((long long)b * slots + slab % slots) * (4 * g.G);
+    for (int i = threadIdx.x; i < 4 * g.G; i += 256) atomicAdd(p + i, gacc[i]);
   } else {
     float* p = part + ((long long)b * g.nslab + slab) * (2 * g.G);
-    for (int i = threadIdx.x; i < 2 * g.G; i += 256) p[i] = gacc[i];
+    for (int i = threadIdx.x; i < 2 * g.G; i += 256) p[i] = (float)vn_fx_decode(gacc[2 * i], gacc[2 * i + 1]);
   }
 }
 
@@ -175,12 +171,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GNGeom g, const float*
 // mean / rstd of one (sample, group) from the (sum, sum of squares) slots a GEMM epilogue accumulated
 __device__ __forceinline__ void gn_stat_from_sums(const GNGeom& g, const float* sums, int slots, int b, int gi, float eps,
                                                   float& m, float& r) {
-  double s0 = 0.0, s1 = 0.0;
+  vn_u64 t[4] = {0, 0, 0, 0};  // integer totals over the slots: the same bits whatever order the producers arrived in
   for (int sl = 0; sl < slots; ++sl) {
-    const float* p = sums + (((long long)b * slots + sl) * g.G + gi) * 2;
-    s0 += (double)p[0];
-    s1 += (double)p[1];
+    const vn_u64* p = reinterpret_cast<const vn_u64*>(sums) + (((long long)b * slots + sl) * g.G + gi) * 4;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t[w] += p[w];
   }
+  const double s0 = vn_fx_decode(t[0], t[1]), s1 = vn_fx_decode(t[2], t[3]);
   const double n = (double)g.HW * g.cpg;
   const double mu = s0 / n;
   double var = s1 / n - mu * mu;
@@ -192,12 +189,13 @@ __device__ __forceinline__ void gn_stat_from_sums(const GNGeom& g, const float* 
 // backward coefficients (S1 / n, S2 / n) of one (sample, group) from slot sums
 __device__ __forceinline__ void gn_coef_from_sums(const GNGeom& g, const float* sums, int slots, int b, int gi, float& c1,
                                                   float& c2) {
-  double s0 = 0.0, s1 = 0.0;
+  vn_u64 t[4] = {0, 0, 0, 0};  // integer totals over the slots: the same bits whatever order the producers arrived in
   for (int sl = 0; sl < slots; ++sl) {
-    const float* p = sums + (((long long)b * slots + sl) * g.G + gi) * 2;
-    s0 += (double)p[0];
-    s1 += (double)p[1];
+    const vn_u64* p = reinterpret_cast<const vn_u64*>(sums) + (((long long)b * slots + sl) * g.G + gi) * 4;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t[w] += p[w];
   }
+  const double s0 = vn_fx_decode(t[0], t[1]), s1 = vn_fx_decode(t[2], t[3]);
   const double n = (double)g.HW * g.cpg;
   c1 = (float)(s0 / n);
   c2 = (float)(s1 / n);
@@ -804,8 +802,9 @@ extern "C" int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long l
 }
 
 extern "C" int vneti_groupnorm_fwd_sums(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
-                                        const float* beta, const float* sums, int slots, float* mean, float* rstd,
+                                        const float* beta, const void* sums_v, int slots, float* mean, float* rstd,
                                         int Bn, int HW, int C, int G, float eps, int silu, void* stream) {
+  const float* sums = reinterpret_cast<const float*>(sums_v);  // 64-bit fixed-point words, see common.h (typed float* internally)
   GNGeom g;
   VN_REQUIRE(gn_geom(g, Bn, HW, C, G) == 0, "groupnorm: unsupported shape B=%d HW=%d C=%d G=%d", Bn, HW, C, G);
   VN_REQUIRE(x && y && gamma && beta && sums && mean && rstd && slots > 0, "groupnorm_fwd_sums: null pointer");
@@ -829,8 +828,9 @@ extern "C" int vneti_groupnorm_fwd_sums(const void* x, long long ldx, void* y, l
 // straight into caller-zeroed slot sums and the apply kernel finishes them (no finalize launch).  Small tensors take the
 // same one-launch kernel as vneti_groupnorm_fwd / _bwd (sums untouched).
 extern "C" int vneti_groupnorm_fwd_2l(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
-                                      const float* beta, float* sums, int slots, float* mean, float* rstd, int Bn, int HW,
+                                      const float* beta, void* sums_v, int slots, float* mean, float* rstd, int Bn, int HW,
                                       int C, int G, float eps, int silu, void* stream) {
+  float* sums = reinterpret_cast<float*>(sums_v);  // 64-bit fixed-point words, see common.h (typed float* internally)
   GNGeom g;
   VN_REQUIRE(gn_geom(g, Bn, HW, C, G) == 0, "groupnorm: unsupported shape B=%d HW=%d C=%d G=%d", Bn, HW, C, G);
   VN_REQUIRE(x && y && gamma && beta && mean && rstd && sums && slots > 0, "groupnorm_fwd_2l: null pointer");
@@ -846,7 +846,7 @@ extern "C" int vneti_groupnorm_fwd_2l(const void* x, long long ldx, void* y, lon
 
 extern "C" int vneti_groupnorm_bwd_2l(const void* dy, long long lddy, const void* x, long long ldx, const float* gamma,
                                       const float* beta, const float* mean, const float* rstd, void* dx, long long lddx,
-                                      const void* dx_accum, long long ldacc, float* sums, int slots, float* ws, int Bn,
+                                      const void* dx_accum, long long ldacc, void* sums_v, int slots, float* ws, int Bn,
                                       int HW, int C, int G, int silu, void* stream);
 
 extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x, long long ldx,
@@ -892,8 +892,9 @@ extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x
 
 extern "C" int vneti_groupnorm_bwd_2l(const void* dy, long long lddy, const void* x, long long ldx, const float* gamma,
                                       const float* beta, const float* mean, const float* rstd, void* dx, long long lddx,
-                                      const void* dx_accum, long long ldacc, float* sums, int slots, float* ws, int Bn,
+                                      const void* dx_accum, long long ldacc, void* sums_v, int slots, float* ws, int Bn,
                                       int HW, int C, int G, int silu, void* stream) {
+  float* sums = reinterpret_cast<float*>(sums_v);  // 64-bit fixed-point words, see common.h (typed float* internally)
   GNGeom g;
   VN_REQUIRE(gn_geom(g, Bn, HW, C, G) == 0, "groupnorm: unsupported shape B=%d HW=%d C=%d G=%d", Bn, HW, C, G);
   VN_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && sums && slots > 0, "groupnorm_bwd_2l: null pointer");

@@ -250,11 +250,11 @@ class Schedule:
     GN2_MAX = 512  # (forward, backward) slot-sum slices of a schedule: 2 per GroupNorm
 
     def _gn2_slice(self):
-        """[B, GN_SLOTS, G, 2] floats of the schedule's slot-sum arena (zeroed by one launch at the head of `fwd`): the
+        """[B, GN_SLOTS, G, 4] 64-bit words (fixed-point sum, sum of squares: csrc/common.h vn_fx_*) of the schedule's slot-sum arena (zeroed by one launch at the head of `fwd`): the
         statistics pass of a big GroupNorm adds its slab sums there and the apply kernel finishes them
         (vneti_groupnorm_fwd_2l / _bwd_2l); small GroupNorms never touch it"""
         if not hasattr(self, "_gn2_arena"):
-            self._gn2_arena = self._buf((self.GN2_MAX, self.B, self.GN_SLOTS, self.groups, 2), torch.float32, zero=True)
+            self._gn2_arena = self._buf((self.GN2_MAX, self.B, self.GN_SLOTS, self.groups, 4), torch.int64, zero=True)
             self._gn2_used = 0
         assert self._gn2_used < self.GN2_MAX
         self._gn2_used += 1
@@ -302,7 +302,7 @@ class Schedule:
             todo.append(rec)
         if not todo:
             return 0
-        self.gn_sums = self._buf((len(todo), B, S, G, 2), torch.float32, zero=True)
+        self.gn_sums = self._buf((len(todo), B, S, G, 4), torch.int64, zero=True)
         for i, rec in enumerate(todo):
             sums = self.gn_sums[i]
             f = self.fwd[rec["prod"]]

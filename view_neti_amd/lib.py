@@ -160,6 +160,8 @@ SIGNATURES = {
     "rng_advance": [c_vp, c_vp],
     "sample_add_noise": [c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                          c_vp],
+    "latent_sample": [c_vp, c_ll, c_vp, c_f, c_vp, c_int, c_int, c_int, c_vp],
+    "add_noise": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "cfg_sampler_step": [c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_vp],
     "cfg_sampler_step_table": [c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_vp, c_vp, c_int, c_vp],
     "table_fill_i64": [c_vp, c_int, c_vp, c_vp, c_vp],

@@ -249,6 +249,29 @@ def sample_add_noise(moments, eps, noise, t, ac, scaling, vpred, latents, noisy,
             1 if vpred else 0, _p(latents), _p(noisy), _p(target), Bn, Lc, HW, stream())
 
 
+def gn_sums_decode(sums: torch.Tensor) -> torch.Tensor:
+    """[..., 4] int64 slot sums (S1.hi, S1.lo, S2.hi, S2.lo: the fixed-point accumulators of csrc/common.h) -> [..., 2]
+    float64 (sum, sum of squares); slots are summed by the caller as integers first (`.sum(dim)` on the int64 tensor)."""
+    import numpy as np
+    a = sums.detach().cpu().numpy().astype(np.int64)
+    out = np.empty(a.shape[:-1] + (2,), dtype=np.float64)
+    for q in range(2):
+        hi, lo = a[..., 2 * q].astype(object), a[..., 2 * q + 1].astype(object)
+        # total * 2^40 = lo + k * 2^64 with k the integer that brings it next to hi * 2^36 (exact in Python integers)
+        k = np.vectorize(lambda h, l: (h * 2 ** 36 - l + 2 ** 63) // 2 ** 64, otypes=[object])(hi, lo)
+        out[..., q] = np.vectorize(lambda l, kk: float(l + kk * 2 ** 64) / 2.0 ** 40, otypes=[np.float64])(lo, k)
+    return torch.from_numpy(out)
+
+
+def latent_sample(moments, eps, scaling, latents, Bn, Lc, HW):
+    _l.call("latent_sample", _p(moments), _ld(moments), _p(eps), scaling, _p(latents), Bn, Lc, HW, stream())
+
+
+def add_noise(latents, noise, t, ac, vpred, noisy, target, Bn, Lc, HW):
+    _l.call("add_noise", _p(latents), _p(noise), _p(t), _p(ac), 1 if vpred else 0, _p(noisy), _p(target), Bn, Lc, HW,
+            stream())
+
+
 def cfg_sampler_step(pred, x, m_prev, x_in, Bn, Lc, HW, guidance, alpha_t, sigma_t, cx, c0, c1, v_prediction):
     _l.call("cfg_sampler_step", _p(pred), _ld(pred), _p(x), _p(m_prev), _p(x_in), Bn, Lc, HW, guidance, alpha_t,
             sigma_t, cx, c0, c1, 1 if v_prediction else 0, stream())
