@@ -71,3 +71,34 @@ def test_dp_two_ranks_equal_single_process(tmp_path):
         g1, _ = _grads([33.0, 444.0, 555.0, 999.0], sd, w_enc)
         params, m, v = R.adamw_step(params, (g0 + g1) / 2, m, v, step, 8e-3)
     assert torch.allclose(res["params"], params, rtol=1e-5, atol=1e-7)
+
+
+def _worker_cfg4(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from view_neti_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_obj, K = 141696, 88  # NeTIMapper(1024-wide CLIP, hidden 64): train_m3_88scenes.yaml
+    total = (K + 1) * n_obj
+    g = torch.full((total,), float(rank + 1))
+    active = 37
+    plan = parallel.reduce_plan(n_obj, K, active, total)
+    moved = parallel.all_reduce_plan_(g, plan)
+    if rank == 0:
+        torch.save({"moved": moved, "plan": plan, "active": g[active * n_obj:(active + 1) * n_obj].clone(),
+                    "view": g[K * n_obj:].clone(), "other": g[:n_obj].clone(), "bucket_bytes": total * 4}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp_config4_reduces_only_the_active_scene_and_the_view_mapper(tmp_path):
+    """BASELINE config 4 (learnable_mode 3, 88 scenes, SD-2.1 widths): every rank trains the same scene per step, so the
+    exchange is that scene's object mapper + the view mapper — 2 x 141 696 floats = 1.13 MB of the 50.4 MB bucket."""
+    out = str(tmp_path / "cfg4.pt")
+    port = 29600 + (os.getpid() % 300)
+    mp.spawn(_worker_cfg4, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["bucket_bytes"] == 89 * 141696 * 4 and r["moved"] == 2 * 141696 * 4
+    assert len(r["plan"]) == 2
+    assert bool((r["active"] == 3.0).all()) and bool((r["view"] == 3.0).all())  # rank 0 (1.0) + rank 1 (2.0)
+    assert bool((r["other"] == 1.0).all()), "segments of other scenes must not move"

@@ -331,3 +331,76 @@ def test_full_size_matches_oracle(cfg_name, B, H, W, with_view):
     assert rel < 1e-3, "predicted-noise MSE must match the oracle to 1e-3 relative"
     assert lat < 2e-3 and pred_rel < 1e-2
     assert cos > 0.999 and gerr < 5e-2
+
+
+@pytest.mark.timeout(2400)
+def test_config4_at_size_88_scene_mappers():
+    """BASELINE config 4 at its real size on one GPU (train_m3_88scenes.yaml; training/coach.py:505-552, dataset.py:584-600):
+    learnable_mode 3, SD-2.1 shapes, 384x512 DTU frames, train_batch_size 3, gradient accumulation 3, 88 object mappers
+    (hidden 64, 1024-wide CLIP: 141 696 floats each) + the view mapper in ONE bucket (12.6 M floats, 89 AdamW segments).
+    Six optimisation steps (18 captured micro-steps) over a seeded scene sequence; the bucket must follow
+    torch.optim.AdamW fed with the engine's own gradients (untouched scenes never move, touched ones keep decaying)."""
+    import time
+    import numpy as np
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.step import TrainStepEngine
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    B, H, W, K, accum, lr = 3, 384, 512, 88, 3, 1e-3 * 3 * 3
+    cfg = sc.CONFIGS["sd21"]()
+    D = cfg.clip.hidden_size
+    assert D == 1024
+    dev = "cuda"
+    uw, vw, cw = synth.unet_weights(cfg.unet, device=dev), synth.vae_weights(cfg.vae, device=dev), synth.clip_weights(cfg.clip, device=dev)
+    gen = torch.Generator().manual_seed(7)
+    base = init_mapper_state(64, 64, D)
+    mk = lambda: {k: v + 0.02 * torch.randn(v.shape, generator=gen) for k, v in base.items()}
+    objs = [mk() for _ in range(K)]
+    sdv = mk()
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    w_enc_v = fourier_frequencies([0.03, 2.0] + [2.0] * 12, 64, 0)
+    eng = TrainStepEngine(cfg, uw, vw, cw, B, H, W, objs, w_enc, 0.4, 5.0, mapper_view=sdv, w_enc_view=w_enc_v,
+                          norm_scale_view=0.35, alpha_view=5.0, lr=lr, seed=11, device_rng=True, grad_accum=accum)
+    del uw, vw, cw
+    n = eng.n_obj
+    assert n == 141696 and eng.n_objects == K and eng.params.numel() == (K + 1) * n == 12_610_944
+    print(f"[config 4] bucket {(K + 1) * n * 4 / 2 ** 20:.1f} MiB ({K} object mappers + view), engine {eng.memory_bytes() / 2 ** 30:.1f} GiB")
+    ph, phv = cfg.clip.vocab_size - 3, cfg.clip.vocab_size - 4
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size, view_placeholder_id=phv)
+    vparams = synth.gaussian((B, 12), 9).clamp(-1, 1)
+    px = synth.pixel_values(B, H, W)
+    ref = [torch.nn.Parameter(eng.params[i * n:(i + 1) * n].cpu().clone()) for i in range(K + 1)]
+    opt = torch.optim.AdamW(ref, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    np.random.seed(0)  # dataset.py:584-600: np.random.choice(len(train_data_subsets)) once per optimisation step
+    scenes = [int(np.random.choice(K)) for _ in range(6)]
+    scenes[3] = scenes[0]  # revisit a scene: its Adam moments must have kept decaying in between
+    eng.set_batch(px, ids, torch.full((B,), ph), torch.full((B,), phv), vparams, object_index=scenes[0])
+    eng.capture()
+    t0 = None
+    for it, k in enumerate(scenes):
+        if it == 1:
+            torch.cuda.synchronize()
+            t0 = time.time()
+        before = eng.params.clone()
+        for _ in range(accum):
+            eng.set_batch(px, ids, torch.full((B,), ph), torch.full((B,), phv), vparams, object_index=k)
+            stepped = eng.step()
+        assert stepped
+        g = (eng.grads / (eng.scaler[0] * eng.hyper[5])).cpu()
+        assert torch.isfinite(g).all() and g[k * n:(k + 1) * n].abs().sum() > 0 and g[K * n:].abs().sum() > 0
+        # (segments of scenes trained earlier keep their last gradient in the bucket; the optimizer reads the active
+        #  scene's segment and the view mapper only — the moved / not-moved check below is the observable)
+        opt.zero_grad(set_to_none=False)
+        ref[k].grad = g[k * n:(k + 1) * n].clone()
+        ref[K].grad = g[K * n:].clone()
+        opt.step()
+        touched = set(scenes[: it + 1])
+        moved = [(not torch.equal(before[j * n:(j + 1) * n], eng.params[j * n:(j + 1) * n])) for j in range(K)]
+        assert [j for j in range(K) if moved[j]] == sorted(touched), (it, sorted(touched))
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) / (5 * accum) * 1e3
+    got = eng.params.cpu()
+    want = torch.cat([p.detach() for p in ref])
+    err = ((got - want).abs().max() / lr).item()
+    print(f"[config 4] scenes {scenes}: max |dp|/lr vs torch.optim.AdamW {err:.3e}; {ms:.1f} ms per micro-step "
+          f"(bs {B}, 384x512, sd21) = {1e3 / ms:.1f} micro-steps/s; opt_step {eng.opt_step.item()}")
+    assert err < 0.05 and eng.opt_step.item() == len(scenes)

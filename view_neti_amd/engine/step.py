@@ -231,14 +231,9 @@ class TrainStepEngine:
         (the 1/world_size is folded into AdamW).  With several object mappers every rank trains the
         same scene per step (same scene-sampler seed), so only that segment and the view mapper move."""
         if self.world_size > 1:
-            from ..parallel import all_reduce_sum_
-            if self.n_objects == 1:
-                all_reduce_sum_(self.grads)
-            else:
-                k = self.active_object
-                all_reduce_sum_(self.grads[k * self.n_obj:(k + 1) * self.n_obj])
-                if self.grads.numel() > self.n_all_obj:
-                    all_reduce_sum_(self.grads[self.n_all_obj:])
+            from ..parallel import all_reduce_plan_, reduce_plan
+            self.last_reduce_bytes = all_reduce_plan_(
+                self.grads, reduce_plan(self.n_obj, self.n_objects, self.active_object, self.grads.numel()))
 
     def step_eager(self):
         """one micro-step; the optimizer runs after every `grad_accum`-th micro-step."""

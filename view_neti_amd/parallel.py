@@ -25,6 +25,28 @@ def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def reduce_plan(n_obj: int, n_objects: int, active: int, total: int):
+    """Which slices of the flat mapper-gradient bucket [object mapper 0 .. K-1 | view mapper] one optimisation step has to
+    exchange: everything for a single object mapper; with several (learnable_mode 3, one mapper per scene,
+    training/coach.py:505-552) only the scene every rank trained this step and the shared view mapper — 1.13 MB instead
+    of the 50.4 MB bucket at BASELINE config 4 (88 scenes, SD-2.1 widths)."""
+    if n_objects == 1:
+        return [(0, total)]
+    plan = [(active * n_obj, (active + 1) * n_obj)]
+    if total > n_objects * n_obj:
+        plan.append((n_objects * n_obj, total))
+    return plan
+
+
+def all_reduce_plan_(flat: torch.Tensor, plan) -> int:
+    """sum the planned slices over ranks in place; returns the payload bytes handed to the collective"""
+    moved = 0
+    for a, b in plan:
+        all_reduce_sum_(flat[a:b])
+        moved += (b - a) * flat.element_size()
+    return moved
+
+
 def data_seed(base_seed: int, rank: int) -> int:
     """rank r draws its own images / noise / timesteps; mapper initialisation uses the SAME seed on
     every rank (the reference re-seeds with torch.manual_seed(0) inside every mapper constructor)."""
