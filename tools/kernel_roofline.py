@@ -38,6 +38,29 @@ def cost(f):
     if fn is ops.layernorm_fwd:
         x, y = a[0], a[1]
         return ("LayerNorm fwd", 0, x.numel() * x.element_size() + y.numel() * y.element_size())
+    if getattr(f, "vn_cost", None) is not None:  # closures tagged where they are built (engine/schedule.py)
+        return (f.vn_cost[0], 0, f.vn_cost[1])
+    if getattr(fn, "__name__", "") == "_ln_bwd":  # partial(self._ln_bwd, rec, dy, dx, accum[, f16_copy])
+        x = a[0]["x"]
+        n = x.numel()
+        extra = (a[3].numel() * a[3].element_size() if a[3] is not None else 0) + (n * 2 if len(a) > 4 and a[4] is not None else 0)
+        return ("LayerNorm bwd", 0, n * x.element_size() + a[1].numel() * a[1].element_size() + a[2].numel() * a[2].element_size() + extra)
+    if fn in (ops.groupnorm_bwd, ops.groupnorm_bwd_2l):
+        x = a[1]
+        return ("GroupNorm(+SiLU) bwd", 0, 5.0 * x.numel() * 2)
+    if fn is ops.add:
+        return ("elementwise glue (add, 2x2 sum, transposes, noise, loss)", 0, sum(t.numel() * t.element_size() for t in a[:3]))
+    if fn is ops.sum2x2:
+        return ("elementwise glue (add, 2x2 sum, transposes, noise, loss)", 0, a[0].numel() * 2 + a[1].numel() * 2)
+    if fn in (ops.sample_add_noise, ops.mse_loss_grad, getattr(ops, "transpose", None), getattr(ops, "timestep_embedding", None)):
+        return ("elementwise glue (add, 2x2 sum, transposes, noise, loss)", 0,
+                sum(t.numel() * t.element_size() for t in a if isinstance(t, torch.Tensor)))
+    if fn is ops.layernorm_bwd:
+        return ("LayerNorm bwd", 0, sum(t.numel() * t.element_size() for t in (a[0], a[1], a[5])))
+    if fn is ops.conv3x3_in:
+        return ("VAE conv_in (direct)", 0, a[0].numel() * 4 + a[3].numel() * 2)
+    if fn is ops.softmax_rows:
+        return ("softmax rows (VAE mid attention)", 0, 2.0 * a[0].numel() * 2)
     if fn is ops.geglu_fwd:
         return ("GEGLU fwd", 0, a[0].numel() * 2 + a[1].numel() * 2)
     if fn is ops.geglu_bwd:
@@ -49,7 +72,13 @@ launches = eng.launches()
 classes = {}
 for f in launches:
     c = cost(f)
-    name = c[0] if c else "other (GN/LN backward closures, glue)"
+    if c is None:
+        # the small launches of the text path (mapper, embeddings, bypass), the device RNG and the glue: latency-bound; their
+        # byte count is every tensor argument once (an upper bound of what they move)
+        args = list(getattr(f, "args", ())) + list((getattr(f, "keywords", None) or {}).values())
+        c = ("small launches (text path, RNG, layout glue)", 0,
+             float(sum(t.numel() * t.element_size() for t in args if isinstance(t, torch.Tensor))) or 1.0)
+    name = c[0]
     d = classes.setdefault(name, dict(fs=[], flops=0.0, bytes=0.0))
     d["fs"].append(f)
     if c:

@@ -51,9 +51,14 @@ __device__ __forceinline__ u32x4 as_u32x4(half8 v) { return __builtin_bit_cast(u
 __device__ __forceinline__ half4 as_half4(u32x2 v) { return __builtin_bit_cast(half4, v); }
 __device__ __forceinline__ u32x2 as_u32x2(half4 v) { return __builtin_bit_cast(u32x2, v); }
 
-__device__ __forceinline__ float vn_silu(float x) { return x / (1.f + __expf(-x)); }
-__device__ __forceinline__ float vn_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float vn_quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+// sigmoid family on the raw transcendental unit: exp(-x) = v_exp_f32(-x * log2 e) and ONE v_rcp_f32 (1 ulp) instead of an
+// IEEE division (v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup: ~10 VALU issues per element in the
+// GroupNorm+SiLU passes and the GEMM epilogues); results are rounded to f16 right after, far above the 1-ulp f32 difference.
+__device__ __forceinline__ float vn_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ float vn_silu(float x) { return x * vn_sigmoid(x); }
+__device__ __forceinline__ float vn_quick_gelu(float x) { return x * vn_sigmoid(1.702f * x); }
 // Exact (erf) GELU without libm's erff (~40 instructions): Phi(x) = 0.5 * erfc(-x / sqrt 2) with erfc from Abramowitz &
 // Stegun 7.1.26 (|error| < 1.5e-7, far below the f16 the result is rounded to), evaluated on the erfc side so the
 // negative tail has no 1 - erf cancellation.  exp(-x^2 / 2) is shared with the derivative: gelu'(x) = Phi(x) + x phi(x).

@@ -267,6 +267,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
       c2hi = c2[b * g.G + g1];
     }
     int r = r0 + ty;
+    float sc[8], sh[8];  // forward: y = x * sc + sh per channel of this thread's chunk
+    if (!BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool lo = j < split;
+        sc[j] = (lo ? rlo : rhi) * ga[j];
+        sh[j] = fmaf(-(lo ? mlo : mhi), sc[j], be[j]);
+      }
+    }
     if (!BWD) {
       // forward: four rows in flight per thread (a single 16-byte load per trip leaves HBM latency exposed:
       // 3.5 TB/s measured on the VAE's 512x512x128 tensors)
@@ -281,9 +290,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
           half8 ov;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const bool lo = j < split;
-            float xh = ((float)xv[u][j] - (lo ? mlo : mhi)) * (lo ? rlo : rhi);
-            float z = xh * ga[j] + be[j];
+            float z = fmaf((float)xv[u][j], sc[j], sh[j]);  // (x - mean) * rstd * gamma + beta, folded per channel
             if (SILU) z = vn_silu(z);
             ov[j] = (half_t)z;
           }

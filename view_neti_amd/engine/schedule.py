@@ -101,12 +101,18 @@ class Schedule:
         if t.gw:
             if extra is not None:
                 self.bwd.append(partial(ops.add, g, extra, g))
-            self.bwd.append(partial(fn, g, g))
+            self.bwd.append(self._tagged(partial(fn, g, g), fn))
         else:
-            self.bwd.append(partial(fn, g, extra))
+            self.bwd.append(self._tagged(partial(fn, g, extra), fn))
             t.gw = True
             for c in t.children:
                 c.gw = True
+
+    @staticmethod
+    def _tagged(p, fn):
+        if hasattr(fn, "vn_cost"):
+            p.vn_cost = fn.vn_cost
+        return p
 
     def _contrib_gemm(self, t: T, A, Bm, **kw):
         """gradient contribution computed by a GEMM (accumulates through the fused residual)."""
@@ -344,12 +350,17 @@ class Schedule:
     def _gn_bwd_fn(self, rec, dy):
         x = rec["x"]
         if "bsums" not in rec:
-            return lambda out, accum: ops.groupnorm_bwd(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
-                                                        self.gn_ws, self.B, rec["hw"], x.cols, self.groups,
-                                                        rec["silu"], accum=accum)
-        return lambda out, accum: ops.groupnorm_bwd_2l(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
-                                                       rec["bsums"], self.GN_SLOTS, self.gn_ws, self.B, rec["hw"], x.cols,
-                                                       self.groups, rec["silu"], accum=accum)
+            fn = lambda out, accum: ops.groupnorm_bwd(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
+                                                      self.gn_ws, self.B, rec["hw"], x.cols, self.groups,
+                                                      rec["silu"], accum=accum)
+        else:
+            fn = lambda out, accum: ops.groupnorm_bwd_2l(dy, x.v, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], out,
+                                                         rec["bsums"], self.GN_SLOTS, self.gn_ws, self.B, rec["hw"], x.cols,
+                                                         self.groups, rec["silu"], accum=accum)
+        # (tools/kernel_roofline.py: launch class and algorithmic bytes — dy and x read in the statistics pass and again
+        #  in the apply pass, dx written once)
+        fn.vn_cost = ("GroupNorm(+SiLU) bwd", 5.0 * self.B * rec["hw"] * x.cols * 2)
+        return fn
 
     def _conv_desc(self, Hi, Wi, Ci, Ho, Wo, stride, pad, ups, ldx, mode=1):
         return dict(mode=mode, Hi=Hi, Wi=Wi, Ci=Ci, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad, pad_l=pad, ups=ups,
