@@ -41,7 +41,7 @@ TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3
               7: "gemm_kernel<256,128,64,32,ring3>", 8: "gemm_kernel<256,128,64,32>", 9: "gemm_kernel<128,128,64,32>",
               10: "gemm_kernel<128,128,64,32,ring3>", 11: "gemm_kernel<128,64,64,32,ring3>", 12: "gemm_kernel<64,64,32,32,ring3>",
               13: "gemm_kernel<128,128,64,32,ring4>", 14: "gemm_kernel<128,64,64,32,ring4>", 15: "gemm_kernel<64,64,32,32,ring4>",
-              16: "gemm8_kernel<256,256,8-phase>"}
+              16: "gemm8_kernel<256,256,8-phase>", 17: "gemm8_kernel<256,128,8-phase>"}
 # algorithmic FLOPs per sample at 512^2, SD-1.5: VAE 1116.7 + CLIP 16x13.3 + UNet fwd 803.3
 # + UNet dgrad 929.4 + CLIP dgrad 216 GF
 ALGO_GFLOP_PER_SAMPLE_512 = 3278.0
@@ -141,7 +141,8 @@ def pmc_traffic(tile_name: str):
     pats = ["gemm_kernel<" + ", ".join(dims) + ", false, true, " + stages,
             "gemm_kernelILi" + "ELi".join(dims) + "ELb0ELb1ELi" + stages + "E"]
     if tile_name.startswith("gemm8_kernel"):
-        pats = ["gemm8_kernel"]
+        bn = dims[1]
+        pats = ["gemm8_kernel<" + bn + ",", "gemm8_kernelILi" + bn + "E"]
     try:
         ks = json.load(open(files[-1]))["kernels"]
     except (OSError, ValueError, KeyError):

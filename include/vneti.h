@@ -73,7 +73,8 @@ typedef struct vneti_gemm_desc {
                          7: the same ring with 16 waves (64x32 wave tiles), 8: 256x128 / 16 waves, 9: 128x128 / 8 waves,
                          10 / 11 / 12: the 3-stage ring on 128x128 (8 waves) / 128x64 / 64x64 (under-filled grids: 2 stages in flight);
                          13 / 14 / 15: the same three tiles with a 4-stage ring (three stages in flight: short-K, latency-bound launches);
-                         16: 256x256 as 8 waves in the 8-phase ping-pong structure (csrc/gemm8.hip; f16 out, tap-major convs);
+                         16 / 17: 256x256 / 256x128 as 8 waves in the 8-phase ping-pong structure (csrc/gemm8.hip; f16 out,
+                         tap-major convs without fused upsampling; other launches fall back to 5 / 7);
                          +100 selects the register-staged (non LDS-DMA) reference variant */
   /* split-K: f32 partials go to `workspace` (>= split_k*batch*M*N*4 bytes) and a second kernel
      reduces them and applies the epilogue.  split_k 0 = heuristic (only if a workspace is given),

@@ -49,7 +49,7 @@ def check(name, got, ref, tol, elem_k=ELEM_K):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 101, 102, 103, 104, 105])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 101, 102, 103, 104, 105])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (128, 64, 64), (77 * 4, 1280, 768), (1000, 8, 192)])
 def test_gemm_plain(hint, M, N, K):
     ops = _ops()
@@ -109,7 +109,7 @@ def test_gemm_f32_out_rowadd_act_batch():
     check("gemm batched", outb, Ab.float() @ B.float().t(), 2e-3)
 
 
-@pytest.mark.parametrize("hint", [3, 16])
+@pytest.mark.parametrize("hint", [3, 16, 17])
 @pytest.mark.parametrize("split", [2, 3, 5, 0])
 @pytest.mark.parametrize("f32", [False, True])
 def test_gemm_split_k(split, f32, hint):
@@ -136,7 +136,7 @@ def test_gemm_split_k(split, f32, hint):
     check(f"gemm split_k={split} f32={f32}", out, ref, 2e-3)
 
 
-@pytest.mark.parametrize("hint", [3, 16])
+@pytest.mark.parametrize("hint", [3, 16, 17])
 @pytest.mark.parametrize("act", [1, 2, 3])
 @pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("N", [328, 324])
@@ -164,7 +164,7 @@ def test_gemm_gate_and_second_output(act, split, N, hint):
     check(f"gemm out2 act{act} split{split}", out2, fn(out.float().cpu()), 1e-3)
 
 
-@pytest.mark.parametrize("hint", [0, 1, 3, 5, 7, 10, 12, 16])
+@pytest.mark.parametrize("hint", [0, 1, 3, 5, 7, 10, 12, 16, 17])
 @pytest.mark.parametrize("M,C", [(300, 64), (1024, 320)])
 def test_gemm_geglu_epilogues(hint, M, C):
     """diffusers FeedForward GEGLU (h, g = proj(x).chunk(2); h * gelu(g)) fused into the GEMM epilogues
@@ -205,7 +205,7 @@ def test_gemm_geglu_epilogues(hint, M, C):
                  workspace=torch.empty(2 * M * 2 * F4, dtype=torch.float32, device=DEV))
 
 
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9, 14, 16])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 5, 7, 9, 14, 16, 17])
 @pytest.mark.parametrize("Bn,HW,C", [(4, 64, 320), (2, 256, 128), (3, 576, 640), (2, 4096, 32 * 4)])
 def test_gemm_groupnorm_sums_and_fused_apply(hint, Bn, HW, C):
     """GroupNorm statistics accumulated by the GEMM epilogue (rows = Bn images of HW pixels, 32 groups) and the
@@ -251,7 +251,7 @@ def _nhwc(x):
 
 @pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
 @pytest.mark.parametrize("case", ["s1", "s2p1", "s2vae", "ups"])
-@pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 13, 15, 16, 101, 103])
+@pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 13, 15, 16, 17, 101, 103])
 def test_conv3x3_fwd(case, hint, korder):
     """both K orders of the implicit GEMM (vneti_gemm_desc.conv_korder): (tap, channel) and (64-channel chunk, tap,
     channel); two chunks so that the orders really differ"""
@@ -283,7 +283,7 @@ def test_conv3x3_fwd(case, hint, korder):
     check(f"conv {case} hint{hint} korder{korder}", out.view(Bn, Ho, Wo, Co), _nhwc(ref), 2e-3)
 
 
-@pytest.mark.parametrize("hint", [3, 16])
+@pytest.mark.parametrize("hint", [3, 16, 17])
 @pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
 @pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("stride,vae", [(1, False), (2, False), (2, True)])

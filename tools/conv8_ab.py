@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from view_neti_amd import ops
 dev = "cuda"
-HINTS = tuple(int(h) for h in os.environ.get("HINTS", "5,16,7,6").split(","))
+HINTS = tuple(int(h) for h in os.environ.get("HINTS", "5,16,7,17").split(","))
 ws = torch.empty(64 * 2 ** 20, dtype=torch.float32, device=dev)
 
 

@@ -8,7 +8,7 @@ import torch
 from view_neti_amd import ops
 
 dev = "cuda"
-HINTS = tuple(int(h) for h in os.environ.get("HINTS", "5,16,7,6").split(","))
+HINTS = tuple(int(h) for h in os.environ.get("HINTS", "5,16,7,17").split(","))
 ops.set_default_gemm_workspace(torch.empty(64 * 2 ** 20, dtype=torch.float32, device=dev))
 
 
@@ -32,26 +32,27 @@ for (M, N, K) in [(256, 256, 64), (256, 256, 128), (256, 256, 192), (256, 256, 5
     A = torch.randn(M, K, generator=g).half().to(dev)
     B = torch.randn(N, K, generator=g).half().to(dev)
     ref = (A.float() @ B.float().t())
-    for rep in range(5):
-        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
-        ops.gemm(A, B, C, tile_hint=16)
-        torch.cuda.synchronize()
-        err = ((C.float() - ref).norm() / ref.norm()).item()
-        mx = (C.float() - ref).abs().max().item()
-        if not (err < 2e-3):
-            bad += 1
-            print(f"MISMATCH M={M} N={N} K={K} rep {rep}: rel {err:.3e} max {mx:.3e} nan {int(torch.isnan(C).sum())}")
-            break
-    else:
-        print(f"ok M={M} N={N} K={K}: rel {err:.2e} max {mx:.2e} (5 runs)")
-    # split-K through the same kernel
-    if K >= 512:
-        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
-        ops.gemm(A, B, C, tile_hint=16, split_k=3)
-        torch.cuda.synchronize()
-        err = ((C.float() - ref).norm() / ref.norm()).item()
-        print(f"   split_k=3: rel {err:.2e}")
-        bad += not (err < 2e-3)
+    for TH in (16, 17):
+        for rep in range(5):
+            C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+            ops.gemm(A, B, C, tile_hint=TH)
+            torch.cuda.synchronize()
+            err = ((C.float() - ref).norm() / ref.norm()).item()
+            mx = (C.float() - ref).abs().max().item()
+            if not (err < 2e-3):
+                bad += 1
+                print(f"MISMATCH tile {TH} M={M} N={N} K={K} rep {rep}: rel {err:.3e} max {mx:.3e} nan {int(torch.isnan(C).sum())}")
+                break
+        else:
+            print(f"ok tile {TH} M={M} N={N} K={K}: rel {err:.2e} max {mx:.2e} (5 runs)")
+        # split-K through the same kernel
+        if K >= 512:
+            C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+            ops.gemm(A, B, C, tile_hint=TH, split_k=3)
+            torch.cuda.synchronize()
+            err = ((C.float() - ref).norm() / ref.norm()).item()
+            print(f"   tile {TH} split_k=3: rel {err:.2e}")
+            bad += not (err < 2e-3)
 print("CORRECTNESS", "FAILED" if bad else "OK")
 
 # ---- time ----

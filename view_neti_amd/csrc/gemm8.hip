@@ -33,13 +33,9 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, NT = 512;
-constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 64 halfs
-constexpr int BUF_BYTES = 4 * HALF_BYTES;  // A0 A1 B0 B1 of one K-tile
-constexpr int CS_LD = BN + 8;
-constexpr int CS_BYTES = BM * CS_LD * 2;
-constexpr int LDS_BYTES = CS_BYTES > 2 * BUF_BYTES ? CS_BYTES : 2 * BUF_BYTES;
-constexpr int GN_IMG = 5, GN_NG = BN / 4 + 2;
+constexpr int BM = 256, NT = 512;
+constexpr int HALF_BYTES = 128 * 128;  // an A half tile: 128 rows x 64 halfs
+constexpr int GN_IMG = 5;
 
 // lab build (-DVN_GEMM8_STAMP, tools/lab/gemm8_stamps.py): thread 0 of every block records s_memtime at the section
 // boundaries into the (otherwise unused) split-K workspace
@@ -55,8 +51,25 @@ constexpr int GN_IMG = 5, GN_NG = BN / 4 + 2;
 #define VN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define VN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int EPI, bool CONV>
+// BN = 256: the structure of the header.  BN = 128 (the N = 128 convolutions of the VAE at 512^2 / 256^2 and the N = 320 / 640
+// layers of the UNet, whose grids the 256-wide tile fills badly): same waves and A half tiles, B half tiles of 64 columns
+// (a wave owns 16 columns of each), THREE K-tile buffers of 48 KiB, and two phases of 16 MFMAs per K-tile:
+//     Q0: read A0(t) B0(t) B1(t) [12 ds_read_b128]   stage A0 B0 B1 of tile t+2 (4 LDS-DMAs)   C00 += A0.B0, C01 += A0.B1   vmcnt(10)
+//     Q1: read A1(t)             [8]                  stage A1 of tile t+2       (2 LDS-DMAs)   C10 += A1.B0, C11 += A1.B1   vmcnt(8)
+// (stream position 12 + 6t .. is issued in tile t; a half tile is read four phases after its staging and restaged two
+// phases after its last read.)
+template <int BN, int EPI, bool CONV>
 __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
+  static_assert(BN == 256 || BN == 128, "tile width");
+  constexpr int NJB = BN / 128;                 // 16-column blocks a wave owns in each B half
+  constexpr int HB_BYTES = (BN / 2) * 128;      // a B half tile
+  constexpr int HB_DMA = BN / 128;              // LDS-DMAs per thread and B half tile (64 rows each)
+  constexpr int NBUF = BN == 256 ? 2 : 3;
+  constexpr int BUF_BYTES = 2 * HALF_BYTES + 2 * HB_BYTES;  // A0 A1 B0 B1 of one K-tile
+  constexpr int CS_LD = BN + 8;
+  constexpr int CS_BYTES = BM * CS_LD * 2;
+  constexpr int LDS_BYTES = CS_BYTES > NBUF * BUF_BYTES ? CS_BYTES : NBUF * BUF_BYTES;
+  constexpr int GN_NG = BN / 4 + 2;
   const half_t* const e_gate = EPI == 2 ? g.gate_src : nullptr;
   half_t* const e_C2 = EPI == 2 ? g.C2 : nullptr;
   const int e_geglu = EPI == 2 ? g.geglu : 0;
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   uint32_t b_base[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int n = n0 + (r >> 1) * 128 + (r & 1) * 64 + lrow;
+    const int n = n0 + (r >> 1) * (BN / 2) + (r & 1) * 64 + lrow;  // (slots with r & 1 are unused when BN = 128)
     b_base[r] = (n < g.N) ? (uint32_t)((long long)n * g.ldb * 2) + gchunk * 16 : VN_OOB;  // + k0 * 2 stays out of range
   }
 
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   // stream) — it runs inside the PREVIOUS phase's MFMA block, where VALU / SALU issue beside the matrix pipe for free —
   // and issue*() is just the two LDS-DMAs, so a phase's load section stays shorter than its partner's 16 MFMAs.
   const int tap_step = (e_conv == 2 ? -1 : 1) * g.ldx2;
-  uint32_t nxt[2];
+  uint32_t nxt[4];  // prepared source offsets: [0..1] an A half, [2..3] B halves (BN = 128: B0 and B1 of one K-tile)
   auto prepA = [&](const int h) {
     const bool live = a_kt[h] < kt_end;  // stagings past the end keep the vmcnt bookkeeping uniform and fetch nothing
     int soff;
@@ -193,11 +206,15 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     for (int j = 0; j < 2; ++j) nxt[j] = (a_mask[2 * h + j] & tapbit) ? (uint32_t)(a_base[2 * h + j] + soff) : VN_OOB;
     a_kt[h] += 1;
   };
-  auto prepB = [&](const int h) {
+  auto prepB = [&](const int h) {  // BN = 256: into nxt[0..1]; BN = 128: into nxt[2 + h]
     const bool live = b_kt[h] < kt_end;
     const uint32_t soff = (uint32_t)b_kt[h] * 128u, dead = live ? 0u : VN_OOB;  // | VN_OOB: beyond any buffer (< 2 GiB)
+    if constexpr (BN == 256) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) nxt[j] = (b_base[2 * h + j] + soff) | dead;
+      for (int j = 0; j < 2; ++j) nxt[j] = (b_base[2 * h + j] + soff) | dead;
+    } else {
+      nxt[2 + h] = (b_base[2 * h] + soff) | dead;
+    }
     b_kt[h] += 1;
   };
   auto issueA = [&](const int h, const int buf) {
@@ -206,9 +223,13 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     for (int j = 0; j < 2; ++j) dma16(rsA, dst + j * 8192, nxt[j]);
   };
   auto issueB = [&](const int h, const int buf) {
-    char* dst = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wave * 1024;
+    char* dst = smem + buf * BUF_BYTES + 2 * HALF_BYTES + h * HB_BYTES + wave * 1024;
+    if constexpr (BN == 256) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(rsB, dst + j * 8192, nxt[j]);
+      for (int j = 0; j < 2; ++j) dma16(rsB, dst + j * 8192, nxt[j]);
+    } else {
+      dma16(rsB, dst, nxt[2 + h]);
+    }
   };
 
   // ---- fragment reads: lane (frow = row of the 16-row block, fq = its 8-wide k chunk inside a k32 sub-step) ----
@@ -221,9 +242,9 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   for (int s = 0; s < 2; ++s) {
     const int ch = ((s * 4 + fq) ^ fkey) << 4;
     rdA[s] = (wr * 64 + frow) * 128 + ch;
-    rdB[s] = 2 * HALF_BYTES + (wc * 32 + frow) * 128 + ch;
+    rdB[s] = 2 * HALF_BYTES + (wc * (16 * NJB) + frow) * 128 + ch;
   }
-  half8 af[4][2], bf0[2][2], bf1[2][2];
+  half8 af[4][2], bf0[NJB][2], bf1[NJB][2];
   auto readA = [&](const int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -231,32 +252,33 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       for (int s = 0; s < 2; ++s)
         af[i][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdA[s] + h * HALF_BYTES + i * 2048));
   };
-  auto readB0 = [&](const int flip) {  // flip = BUF_BYTES: from the other K-tile buffer
+  auto readB0 = [&](const int flip) {  // flip = BUF_BYTES: from the other K-tile buffer (BN = 256)
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
+    for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) bf0[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + (rdB[s] ^ flip) + jb * 2048));
   };
   auto readB1 = [&]() {
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
+    for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        bf1[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdB[s] + HALF_BYTES + jb * 2048));
+        bf1[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdB[s] + HB_BYTES + jb * 2048));
   };
 
   // the bias of this lane's 16 columns, requested before the main loop (its L2 round trip would otherwise sit between
   // the last MFMA and the first C-tile write); out-of-range columns and a null bias read as zeros
-  f32x4 bv[2][2];
+  f32x4 bv[2][NJB];
   {
     const __amdgpu_buffer_rsrc_t rsBias = vn_make_rsrc(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-        bv[j][jb] = __builtin_bit_cast(f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + j * 128 + wc * 32 + jb * 16 + 4 * fq) * 4u));
+      for (int jb = 0; jb < NJB; ++jb)
+        bv[j][jb] = __builtin_bit_cast(
+            f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + j * (BN / 2) + wc * (16 * NJB) + jb * 16 + 4 * fq) * 4u));
   }
-  f32x4 acc[2][2][4][2];
+  f32x4 acc[2][2][4][NJB];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) acc[h][j][i][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jb = 0; jb < NJB; ++jb) acc[h][j][i][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // one quadrant: 16 MFMAs; operands swapped (D[row = n][col = m]) so a lane owns 4 consecutive n of one m.  PREP = the
   // address work of the NEXT phase's staging, free to be scheduled between the MFMAs.
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     __builtin_amdgcn_s_setprio(1);                                                                             \
     PREP;                                                                                                      \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                \
-        _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) acc[H][J][i][jb] =                                    \
+        _Pragma("unroll") for (int jb = 0; jb < NJB; ++jb) acc[H][J][i][jb] =                                  \
             __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[jb][s], af[i][s], acc[H][J][i][jb], 0, 0, 0);           \
     __builtin_amdgcn_s_setprio(0);                                                                             \
   } while (0)
@@ -290,64 +312,133 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);     \
   } while (0)
 
-  // ---- prologue: tile 0 and three half tiles of tile 1 (stream positions 0..6) ----
-  prepB(0);
-  issueB(0, 0);
-  prepA(0);
-  issueA(0, 0);
-  prepB(1);
-  issueB(1, 0);
-  prepA(1);
-  issueA(1, 0);
-  prepB(0);
-  issueB(0, 1);
-  prepA(0);
-  issueA(0, 1);
-  prepB(1);
-  issueB(1, 1);
-  prepA(1);        // A1 of tile 1: issued in phase 0
-  VN_WAIT_VM(10);  // positions 0, 1 (B0, A0 of tile 0) have landed
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  VN_STAMP(1);
-  readB0(0);
-  VN_WAIT_LGKM0();  // retired before the stagger barrier: the slot is restaged in phase 1
-  __builtin_amdgcn_sched_barrier(0);
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (BN == 256) {
+    // ---- prologue: tile 0 and three half tiles of tile 1 (stream positions 0..6) ----
+    prepB(0);
+    issueB(0, 0);
+    prepA(0);
+    issueA(0, 0);
+    prepB(1);
+    issueB(1, 0);
+    prepA(1);
+    issueA(1, 0);
+    prepB(0);
+    issueB(0, 1);
+    prepA(0);
+    issueA(0, 1);
+    prepB(1);
+    issueB(1, 1);
+    prepA(1);        // A1 of tile 1: issued in phase 0
+    VN_WAIT_VM(10);  // positions 0, 1 (B0, A0 of tile 0) have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    VN_STAMP(1);
+    readB0(0);
+    VN_WAIT_LGKM0();  // retired before the stagger barrier: the slot is restaged in phase 1
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
 
-  int cur = 0;
-  for (int t = 0; t < T; ++t) {
-    // P0
-    readA(0);
-    issueA(1, cur ^ 1);
-    VN_PHASE_SYNC();
-    VN_MMA(0, 0, bf0, prepB(0));
-    VN_PHASE_END();
-    // P1
-    readB1();
-    issueB(0, cur);
-    VN_PHASE_SYNC();
-    VN_MMA(0, 1, bf1, prepA(0));
-    VN_PHASE_END();
-    // P2
-    readA(1);
-    issueA(0, cur);
-    VN_PHASE_SYNC();
-    VN_MMA(1, 0, bf0, prepB(1));
-    VN_PHASE_END();
-    // P3
-    readB0(BUF_BYTES);
-    issueB(1, cur);
-    VN_PHASE_SYNC();
-    VN_MMA(1, 1, bf1, prepA(1));
-    VN_PHASE_END();
-    cur ^= 1;
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+      // P0
+      readA(0);
+      issueA(1, cur ^ 1);
+      VN_PHASE_SYNC();
+      VN_MMA(0, 0, bf0, prepB(0));
+      VN_PHASE_END();
+      // P1
+      readB1();
+      issueB(0, cur);
+      VN_PHASE_SYNC();
+      VN_MMA(0, 1, bf1, prepA(0));
+      VN_PHASE_END();
+      // P2
+      readA(1);
+      issueA(0, cur);
+      VN_PHASE_SYNC();
+      VN_MMA(1, 0, bf0, prepB(1));
+      VN_PHASE_END();
+      // P3
+      readB0(BUF_BYTES);
+      issueB(1, cur);
+      VN_PHASE_SYNC();
+      VN_MMA(1, 1, bf1, prepA(1));
+      VN_PHASE_END();
+      cur ^= 1;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      rdA[s] ^= BUF_BYTES;
-      rdB[s] ^= BUF_BYTES;
+      for (int s = 0; s < 2; ++s) {
+        rdA[s] ^= BUF_BYTES;
+        rdB[s] ^= BUF_BYTES;
+      }
     }
+  } else {
+    // two quadrants that share the A fragments: 16 MFMAs (one 16-column block per B half)
+#define VN_MMA2(H, PREP)                                                                                       \
+  do {                                                                                                         \
+    VN_WAIT_LGKM0();                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    PREP;                                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i) {              \
+      acc[H][0][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[0][s], af[i][s], acc[H][0][i][0], 0, 0, 0); \
+      acc[H][1][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[0][s], af[i][s], acc[H][1][i][0], 0, 0, 0); \
+    }                                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+  } while (0)
+#define VN_SYNC(n)                         \
+  do {                                     \
+    VN_WAIT_VM(n);                         \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+    // ---- prologue: tiles 0 and 1 (stream positions 0..11: [A0 A0 B0 B1 | A1 A1] per tile) ----
+#pragma unroll
+    for (int t0 = 0; t0 < 2; ++t0) {
+      prepA(0);
+      prepB(0);
+      prepB(1);
+      issueA(0, t0);
+      issueB(0, t0);
+      issueB(1, t0);
+      prepA(1);
+      issueA(1, t0);
+    }
+    prepA(0);  // tile 2's A0 B0 B1: issued in Q0 of tile 0
+    prepB(0);
+    prepB(1);
+    VN_WAIT_VM(8);  // positions 0..3 (A0, B0, B1 of tile 0) have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    VN_STAMP(1);
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
+    int stg = 2;  // buffer of the tile being staged: (t + 2) % 3
+    for (int t = 0; t < T; ++t) {
+      // Q0
+      readB0(0);
+      readB1();
+      readA(0);
+      issueA(0, stg);
+      issueB(0, stg);
+      issueB(1, stg);
+      VN_SYNC(10);
+      VN_MMA2(0, prepA(1));
+      VN_PHASE_END();
+      // Q1
+      readA(1);
+      issueA(1, stg);
+      VN_SYNC(8);
+      VN_MMA2(1, (prepA(0), prepB(0), prepB(1)));
+      VN_PHASE_END();
+      stg = stg == 2 ? 0 : stg + 1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {  // reads move on to the next buffer: (t + 1) % 3
+        rdA[s] = rdA[s] >= 2 * BUF_BYTES ? rdA[s] - 2 * BUF_BYTES : rdA[s] + BUF_BYTES;
+        rdB[s] = rdB[s] >= 2 * BUF_BYTES ? rdB[s] - 2 * BUF_BYTES : rdB[s] + BUF_BYTES;
+      }
+    }
+#undef VN_MMA2
+#undef VN_SYNC
   }
   VN_STAMP(2);
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
@@ -357,7 +448,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #undef VN_PHASE_SYNC
 #undef VN_PHASE_END
 
-  // acc[h][j][i][jb][e]  <->  block row h*128 + wr*64 + i*16 + frow, block column j*128 + wc*32 + jb*16 + 4*fq + e
+  // acc[h][j][i][jb][e]  <->  block row h*128 + wr*64 + i*16 + frow, block column j*(BN/2) + wc*16*NJB + jb*16 + 4*fq + e
   // ---- split-K: raw f32 partials straight to the workspace ----
   if (g.ksplit > 1) {
     float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
@@ -368,9 +459,9 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int jb = 0; jb < 2; ++jb) {
+          for (int jb = 0; jb < NJB; ++jb) {
             const int m = m0 + h * 128 + wr * 64 + i * 16 + frow;
-            const int n = n0 + j * 128 + wc * 32 + jb * 16 + 4 * fq;
+            const int n = n0 + j * (BN / 2) + wc * (16 * NJB) + jb * 16 + 4 * fq;
             if (m < g.M && n < g.N) {
               float* p = ws + (long long)m * g.N + n;
               if (n + 4 <= g.N && (g.N & 3) == 0) {
@@ -400,9 +491,9 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int jb = 0; jb < 2; ++jb) {
+          for (int jb = 0; jb < NJB; ++jb) {
             const int ml = h * 128 + wr * 64 + i * 16 + frow;
-            const int nl = (j * 128 + wc * 32 + jb * 16 + 4 * fq) ^ nsw;
+            const int nl = (j * (BN / 2) + wc * (16 * NJB) + jb * 16 + 4 * fq) ^ nsw;
             half4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (half_t)apply_act(acc[h][j][i][jb][e] * g.alpha + bv[j][jb][e], e_act);
@@ -420,7 +511,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   const half_t* Rb = reinterpret_cast<const half_t*>(g.resid);
   if (Rb) Rb += (long long)bz * g.strideC;
   constexpr int CPR = BN / 8;
-  constexpr int U = EPI == 2 ? 2 : (EPI == 1 ? 4 : 8);
+  constexpr int U = EPI == 2 ? 2 : (EPI == 1 ? 4 : (BN == 256 ? 8 : 4));
   static_assert(NT % CPR == 0 && CPR <= 32 && (BM * CPR) % NT == 0, "a thread keeps one 8-column chunk over all its rows");
   vn_u64* gacc = reinterpret_cast<vn_u64*>(smem + LDS_BYTES);
   const bool gn = e_gn_sums != nullptr;
@@ -455,16 +546,17 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     s_lo = q_lo = s_hi = q_hi = 0.f;
   };
   const bool full_chunk = n + 8 <= g.N;  // false only in the last column chunk of an N that is no multiple of 8
-  const bool swap_halves = (tid >> 8) & 1;  // rows tid / 32 + 16 * it have bit 3 set for waves 4..7 (see phase 1)
+  const bool swap_halves = ((tid / CPR) >> 3) & 1;  // bit 3 of this thread's rows (the same for all of them, and wave-uniform)
   const __amdgpu_buffer_rsrc_t rsR = vn_make_rsrc(Rb, Rb ? 0x7fffffffu : 0u);
   const __amdgpu_buffer_rsrc_t rsRA = vn_make_rsrc(e_rowadd, e_rowadd ? 0x7fffffffu : 0u);
   const __amdgpu_buffer_rsrc_t rsG = vn_make_rsrc(e_gate, e_gate ? 0x7fffffffu : 0u);
   const int r_first = tid / CPR;
-  for (int it0 = 0; it0 < BM / 16; it0 += U) {
+  constexpr int RPP = NT / CPR;  // rows per pass of the block: 16 (BN = 256) or 32 (BN = 128)
+  for (int it0 = 0; it0 < BM / RPP; it0 += U) {
     half8 cv[U], rv[U], av[U], gv[U], gv2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int r = r_first + 16 * (it0 + u);
+      const int r = r_first + RPP * (it0 + u);
       const int m = m0 + r;
       const bool ok = m < g.M && full_chunk;
       u32x4 t = *reinterpret_cast<const u32x4*>(smem + ((size_t)r * CS_LD + c) * 2);
@@ -488,7 +580,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int r = r_first + 16 * (it0 + u);
+      const int r = r_first + RPP * (it0 + u);
       const int m = m0 + r;
       const bool valid = m < g.M && n < g.N;
       if (gn) {
@@ -615,16 +707,20 @@ inline int epilogue_level8(const GemmArgs& g) {
 
 // f16 output only; the caller (vneti_gemm_f16) has validated the descriptor, set ksplit / kt_per_split and launches the
 // split-K reduce itself.  Returns VNETI_EUNSUP for what this tile does not carry (f32 output, chunk-major conv K order).
-int vneti_launch_gemm8(void* gemm_args, hipStream_t st) {
+int vneti_launch_gemm8(void* gemm_args, int bn, hipStream_t st) {
   GemmArgs& g = *reinterpret_cast<GemmArgs*>(gemm_args);
   if (g.out_f32 || (g.conv_mode && (g.korder || g.ups || (g.conv_mode == 2 && g.stride == 2))) ||
       (g.M >= (1 << 24) && (g.conv_mode || g.rowadd || g.gn_sums)))  // float-reciprocal row arithmetic: rows < 2^24
     return VNETI_EUNSUP;
   g.tiles_m = cdiv(g.M, BM);
-  g.tiles_n = cdiv(g.N, BN);
+  g.tiles_n = cdiv(g.N, bn);
   const dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit), block(NT);
   const int epi = epilogue_level8(g);
-#define VN_GO(E, C) hipLaunchKernelGGL((gemm8_kernel<E, C>), grid, block, 0, st, g)
+#define VN_GO(E, C)                                                                        \
+  do {                                                                                     \
+    if (bn == 256) hipLaunchKernelGGL((gemm8_kernel<256, E, C>), grid, block, 0, st, g);   \
+    else hipLaunchKernelGGL((gemm8_kernel<128, E, C>), grid, block, 0, st, g);             \
+  } while (0)
   if (g.conv_mode) {
     if (epi == 2) VN_GO(2, true); else if (epi == 1) VN_GO(1, true); else VN_GO(0, true);
   } else {

@@ -76,5 +76,5 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 
 }  // namespace
 
-// the 256x256 8-phase tile (gemm8.hip); g.ksplit / g.kt_per_split already set, f16 output only
-int vneti_launch_gemm8(void* gemm_args, hipStream_t st);
+// the 8-phase ping-pong tiles (gemm8.hip): 256 x bn, bn = 256 or 128; g.ksplit / g.kt_per_split already set, f16 output only
+int vneti_launch_gemm8(void* gemm_args, int bn, hipStream_t st);

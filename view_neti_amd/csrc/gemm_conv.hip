@@ -740,10 +740,10 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
 struct TileDims {
   int bm, bn;
 };
-constexpr int kMaxTile = 16;
+constexpr int kMaxTile = 17;
 constexpr TileDims kTiles[kMaxTile + 1] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128}, {256, 256}, {256, 128}, {256, 128},
                                           {256, 128}, {128, 128}, {128, 128}, {128, 64},  {64, 64},   {128, 128}, {128, 64},  {64, 64},
-                                          {256, 256}};
+                                          {256, 256}, {256, 128}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -904,9 +904,10 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   VN_REQUIRE(cfg >= 1 && cfg <= kMaxTile, "gemm: unknown tile_hint %d", d->tile_hint);
   // the 8-phase tile: LDS-DMA only; convolutions whose gather offset is linear in the tap (no fused upsample, no
   // stride-2 transposed gather), tap-major K order
-  if (cfg == 16 && (!dma || (d->conv_mode && (d->conv_korder || d->ups || (d->conv_mode == 2 && d->stride == 2))) ||
-                    (d->M >= (1 << 24) && (d->conv_mode || d->rowadd || d->gn_sums)))) cfg = 5;
-  if ((cfg == 5 || cfg == 16) && f32) cfg = 4;  // the 256x256 tiles' f32 epilogue staging would not fit in LDS
+  if ((cfg == 16 || cfg == 17) && (!dma || (d->conv_mode && (d->conv_korder || d->ups || (d->conv_mode == 2 && d->stride == 2))) ||
+                    (d->M >= (1 << 24) && (d->conv_mode || d->rowadd || d->gn_sums)))) cfg = cfg == 16 ? 5 : 7;
+  if ((cfg == 5 || cfg == 16) && f32) cfg = 4;
+  if (cfg == 17 && f32) cfg = 7;  // the 256x256 tiles' f32 epilogue staging would not fit in LDS
   if ((cfg == 6 || cfg == 7) && !dma) cfg = 4;  // the 3-stage ring exists with LDS-DMA only
   if (cfg >= 10 && !dma) cfg = kTiles[cfg].bm == 128 ? (kTiles[cfg].bn == 128 ? 1 : 2) : 3;
   long long ws_floats = d->workspace ? d->workspace_bytes / 4 : 0;
@@ -945,8 +946,9 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     case 13: return launch_cfg_ring<128, 128, 64, 32, 4>(g, f32, st);
     case 14: return launch_cfg_ring<128, 64, 64, 32, 4>(g, f32, st);
     case 15: return launch_cfg_ring<64, 64, 32, 32, 4>(g, f32, st);
-    case 16: {  // 256x256 as 8 waves in the 8-phase ping-pong structure (gemm8.hip)
-      const int rc = vneti_launch_gemm8(&g, st);
+    case 16:    // 256x256 as 8 waves in the 8-phase ping-pong structure (gemm8.hip)
+    case 17: {  // 256x128, same waves, three K-tile buffers
+      const int rc = vneti_launch_gemm8(&g, cfg == 16 ? 256 : 128, st);
       if (rc != VNETI_OK) return rc;
       launch_reduce(g, st);
       return vneti_check_launch("gemm8_kernel");

@@ -128,7 +128,7 @@ class Schedule:
     _tile_cache: Dict[tuple, int] = {}
     _TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128), 5: (256, 256), 6: (256, 128), 7: (256, 128),
                   8: (256, 128), 9: (128, 128), 10: (128, 128), 11: (128, 64), 12: (64, 64), 13: (128, 128), 14: (128, 64),
-                  15: (64, 64), 16: (256, 256)}
+                  15: (64, 64), 16: (256, 256), 17: (256, 128)}
 
     @staticmethod
     def _gemm_key(f):
@@ -141,7 +141,7 @@ class Schedule:
         ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
         return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32, kw.get("geglu") or 0)
 
-    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16), reps=8):
+    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17), reps=8):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
         tile configuration, with the split-K heuristic and with split-K forced off (the f32 partials
         and the reduce launch are not always worth the extra blocks), and pin the fastest pair.  Launches are
