@@ -725,12 +725,13 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnA
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs a) {
   const int Cc = a.H * a.D;
   const long long rows = (long long)a.Bn * a.Nk;
-  const long long plane = rows * Cc;
-  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= plane / 4) return;
-  const long long e = gid * 4;
-  const long long row = e / Cc;
-  const int c = (int)(e - row * Cc);
+  const long long plane = rows * Cc;  // < 2^31 (77-key cross attention: a few hundred thousand): 32-bit index arithmetic
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= (unsigned)(plane / 4)) return;
+  const unsigned e32 = gid * 4u;
+  const unsigned row32 = e32 / (unsigned)Cc;
+  const int c = (int)(e32 - row32 * (unsigned)Cc);
+  const long long e = e32, row = row32;
   f32x4 k = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < a.qsplit; ++s) {
     k += *reinterpret_cast<const f32x4*>(a.ws + ((long long)s * 2) * plane + e);
@@ -893,6 +894,7 @@ extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* K, l
   DISPATCH_D(attn_dkv_kernel, grid, st, a);
   if (qsplit > 1) {
     long long n4 = (long long)Bn * Nk * H * D / 4;
+    VN_REQUIRE(n4 * 4 < 0x7fffffffLL, "attn_bwd_dkv: q-split reduce indexes with 32 bits");
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, st, a);
   }
   return vneti_check_launch("attn_bwd_dkv");

@@ -129,5 +129,22 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+// n / d for 0 <= n, 0 < d through a float reciprocal (rcp_d = 1 / d, computed once): the float quotient is within one of the
+// true one for n < 2^24 and within a few beyond, and the remainder test makes it exact — a 32-bit integer division is
+// ~40 dependent instructions, this is 6.  Returns the quotient, leaves the remainder in `rem`.
+__device__ __forceinline__ int vn_divmod(int n, int d, float rcp_d, int& rem) {
+  int q = (int)((float)n * rcp_d);
+  int r = n - q * d;
+  while (r < 0) {
+    q -= 1;
+    r += d;
+  }
+  while (r >= d) {
+    q += 1;
+    r -= d;
+  }
+  rem = r;
+  return q;
+}
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }

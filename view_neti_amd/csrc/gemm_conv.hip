@@ -92,6 +92,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   const int gchunk = DMA ? ((tid & 7) ^ ((lrow >> 1) & 7)) : (tid & 7);
 
   // ---- per-thread A row bookkeeping (all 32-bit: every tensor is < 2 GiB) -------------------
+  const float rcp_hw = CONV ? __builtin_amdgcn_rcpf((float)(g.Ho * g.Wo)) : 0.f, rcp_wo = CONV ? __builtin_amdgcn_rcpf((float)g.Wo) : 0.f;
   int a_off[A_IT];  // plain: row byte offset; conv: byte offset of the (py, px) corner pixel
   int a_py[A_IT], a_px[A_IT], a_bh[A_IT];  // conv: corner coords and b*Hi; a_bh < 0 => invalid row
 #pragma unroll
@@ -102,11 +103,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       a_off[i] = ok ? (int)((long long)m * g.lda * 2) + gchunk * 16 : -1;
       a_py[i] = a_px[i] = a_bh[i] = 0;
     } else {
-      int hw = g.Ho * g.Wo;
-      int b = m / hw;
-      int rem = m - b * hw;
-      int oy = rem / g.Wo;
-      int ox = rem - oy * g.Wo;
+      int rem, ox;  // (b, oy, ox) of output pixel m without integer divisions (common.h vn_divmod)
+      const int b = vn_divmod(m, g.Ho * g.Wo, rcp_hw, rem);
+      const int oy = vn_divmod(rem, g.Wo, rcp_wo, ox);
       a_bh[i] = ok ? b * g.Hi : -1;
       if (e_conv == 1) {
         a_py[i] = oy * g.stride - g.pad_t;
@@ -444,6 +443,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     // csrc/norms.hip); its running sums go to the LDS accumulators whenever the image changes and at the end
     vn_u64* gacc = reinterpret_cast<vn_u64*>(smem + LDS_BYTES);
     const bool gn = e_gn_sums != nullptr;
+    const float rcp_gnhw = gn ? __builtin_amdgcn_rcpf((float)g.gn_hw) : 0.f;
+    const float rcp_rpg = e_rowadd ? __builtin_amdgcn_rcpf((float)g.rows_per_group) : 0.f;
     const int gn_img0 = gn ? m0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
     const int gn_c = n0 + (tid % CPR) * 8;
     const int gn_glo = gn ? gn_c / g.gn_cpg : 0;
@@ -477,7 +478,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       int m = m0 + r, n = n0 + c;
       const bool valid = m < g.M && n < g.N;
       if (gn) {
-        const int img = valid ? m / g.gn_hw : gn_img;
+        int gn_rem;
+        const int img = valid ? vn_divmod(m, g.gn_hw, rcp_gnhw, gn_rem) : gn_img;
         if (__any(img != gn_img)) {
           gn_flush();
           gn_img = img;
@@ -485,7 +487,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       }
       if (!valid) continue;
       half8 v = as_half8(*reinterpret_cast<const u32x4*>(smem + ((size_t)r * CS_LD + c) * 2));
-      const half_t* radd = e_rowadd ? e_rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + n : nullptr;
+      int ra_rem;
+      const half_t* radd = e_rowadd ? e_rowadd + (long long)vn_divmod(m, g.rows_per_group, rcp_rpg, ra_rem) * g.ld_rowadd + n : nullptr;
       if (n + 8 <= g.N) {
         if (radd) {
           half8 t = *reinterpret_cast<const half8*>(radd);
@@ -587,14 +590,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 
 // split-K second pass: C = epi(alpha * sum_z ws[z]) with the same fused epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
-  const int n4 = (g.N + 3) / 4;
-  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  long long total = (long long)g.batch * g.M * n4;
+  // 32-bit index arithmetic (the launcher checks batch * M * ceil(N / 4) < 2^31): the 64-bit divisions this used to do cost
+  // more than the reduction itself on the 110 launches per step, all of them a few microseconds long
+  const unsigned n4 = (unsigned)(g.N + 3) / 4;
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+  const unsigned total = (unsigned)g.batch * (unsigned)g.M * n4;
   if (gid >= total) return;
-  const int c = (int)(gid % n4) * 4;
-  const long long row = gid / n4;
-  const int m = (int)(row % g.M);
-  const int bz = (int)(row / g.M);
+  const unsigned row = gid / n4;
+  const int c = (int)(gid - row * n4) * 4;
+  const int bz = g.batch > 1 ? (int)(row / (unsigned)g.M) : 0;
+  const int m = (int)(row - (unsigned)bz * (unsigned)g.M);
   const int ne = min(4, g.N - c);
   const long long zstride = (long long)g.batch * g.M * g.N;
   const float* p0 = g.ws + ((long long)bz * g.M + m) * g.N + c;
@@ -699,7 +704,7 @@ void launch_variant(const GemmArgs& g, dim3 grid, hipStream_t st) {
 
 inline void launch_reduce(const GemmArgs& g, hipStream_t st) {
   if (g.ksplit > 1) {
-    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);
+    long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);  // < 2^31: checked with the workspace size in vneti_gemm_f16
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
   }
 }
@@ -920,6 +925,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     VN_REQUIRE(d->workspace && (long long)ks * batch * d->M * d->N <= ws_floats,
                "gemm: split_k=%d needs %lld workspace bytes", ks, (long long)ks * batch * d->M * d->N * 4);
     VN_REQUIRE(batch == 1 || (d->strideC != 0), "gemm: batched split-K needs strideC");
+    VN_REQUIRE((long long)batch * d->M * ((d->N + 3) / 4) < 0x7fffffffLL, "gemm: split-K output larger than 2^31 chunks");
   }
   g.ksplit = ks;
   g.kt_per_split = cdiv(nk, ks);

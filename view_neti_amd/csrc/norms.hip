@@ -23,7 +23,20 @@ namespace {
 #endif
 struct GNGeom {
   int Bn, HW, C, G, cpg, CC, TX, TY, rps, nslab;
+  double inv_n;  // 1 / (HW * cpg): the statistics are finished with multiplications, not f64 divisions
 };
+
+// mean / rstd from (sum, sum of squares): the cancellation E[x^2] - E[x]^2 in f64, the rest in f32 (v_rsq_f32 + one Newton
+// step) — an f64 division and square root per thread cost the apply kernels more than a thousand cycles before their first load
+__device__ __forceinline__ void vn_mean_rstd(double s0, double s1, double inv_n, float eps, float& m, float& r) {
+  const double mu = s0 * inv_n;
+  const double var = s1 * inv_n - mu * mu;
+  const float v = fmaxf((float)var, 0.f) + eps;
+  float y = __builtin_amdgcn_rsqf(v);
+  y = y * (1.5f - 0.5f * v * y * y);
+  m = (float)mu;
+  r = y;
+}
 
 __device__ __forceinline__ void gn_thread_coords(const GNGeom& g, int& tx, int& ty, bool& active) {
   int tid = threadIdx.x;
@@ -154,16 +167,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GNGeom g, const float*
       s0 += red[0][l * g.G + gi];
       s1 += red[1][l * g.G + gi];
     }
-    const double n = (double)g.HW * g.cpg;
     if (!BWD) {
-      double m = s0 / n;
-      double var = s1 / n - m * m;
-      if (var < 0.0) var = 0.0;
-      o0[b * g.G + gi] = (float)m;
-      o1[b * g.G + gi] = (float)(1.0 / sqrt(var + (double)eps));
+      float m, r;
+      vn_mean_rstd(s0, s1, g.inv_n, eps, m, r);
+      o0[b * g.G + gi] = m;
+      o1[b * g.G + gi] = r;
     } else {
-      o0[b * g.G + gi] = (float)(s0 / n);
-      o1[b * g.G + gi] = (float)(s1 / n);
+      o0[b * g.G + gi] = (float)(s0 * g.inv_n);
+      o1[b * g.G + gi] = (float)(s1 * g.inv_n);
     }
   }
 }
@@ -178,12 +189,7 @@ __device__ __forceinline__ void gn_stat_from_sums(const GNGeom& g, const float* 
     for (int w = 0; w < 4; ++w) t[w] += p[w];
   }
   const double s0 = vn_fx_decode(t[0], t[1]), s1 = vn_fx_decode(t[2], t[3]);
-  const double n = (double)g.HW * g.cpg;
-  const double mu = s0 / n;
-  double var = s1 / n - mu * mu;
-  if (var < 0.0) var = 0.0;
-  m = (float)mu;
-  r = (float)(1.0 / sqrt(var + (double)eps));
+  vn_mean_rstd(s0, s1, g.inv_n, eps, m, r);
 }
 
 // backward coefficients (S1 / n, S2 / n) of one (sample, group) from slot sums
@@ -196,9 +202,8 @@ __device__ __forceinline__ void gn_coef_from_sums(const GNGeom& g, const float* 
     for (int w = 0; w < 4; ++w) t[w] += p[w];
   }
   const double s0 = vn_fx_decode(t[0], t[1]), s1 = vn_fx_decode(t[2], t[3]);
-  const double n = (double)g.HW * g.cpg;
-  c1 = (float)(s0 / n);
-  c2 = (float)(s1 / n);
+  c1 = (float)(s0 * g.inv_n);
+  c2 = (float)(s1 * g.inv_n);
 }
 
 template <bool BWD, bool SILU, bool FROM_SUMS = false>
@@ -218,6 +223,46 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
   int tx, ty;
   bool active;
   gn_thread_coords(g, tx, ty, active);
+  // FROM_SUMS: the statistics pass left fixed-point slot sums; ONE thread per group finishes them for the block (all its
+  // slot loads in flight together) and publishes the two numbers through LDS — every thread walking the slots itself was
+  // `slots` serialised L2 round trips at the head of each block, more than a small slab's whole streaming time
+  __shared__ float s_stat[2][64];
+  if constexpr (FROM_SUMS) {
+    const int gi = threadIdx.x;
+    if (gi < g.G) {
+      vn_u64 t[4] = {0, 0, 0, 0};
+      const vn_u64* p0 = reinterpret_cast<const vn_u64*>(sums) + ((long long)b * slots * g.G + gi) * 4;
+      vn_u64 v[8][4];
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {
+        const vn_u64* p = p0 + (long long)(sl < slots ? sl : 0) * g.G * 4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v[sl][w] = p[w];
+      }
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t[w] += sl < slots ? v[sl][w] : 0;
+      for (int sl = 8; sl < slots; ++sl)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t[w] += p0[(long long)sl * g.G * 4 + w];
+      const double s0 = vn_fx_decode(t[0], t[1]), s1 = vn_fx_decode(t[2], t[3]);
+      if constexpr (!BWD) {
+        float m, r;
+        vn_mean_rstd(s0, s1, g.inv_n, eps, m, r);
+        s_stat[0][gi] = m;
+        s_stat[1][gi] = r;
+        if (slab == 0) {  // published for the backward
+          mean_out[b * g.G + gi] = m;
+          rstd_out[b * g.G + gi] = r;
+        }
+      } else {
+        s_stat[0][gi] = (float)(s0 * g.inv_n);
+        s_stat[1][gi] = (float)(s1 * g.inv_n);
+      }
+    }
+    __syncthreads();
+  }
   if (!active) return;
   const int r0 = slab * g.rps;
   const int r1 = min(r0 + g.rps, g.HW);
@@ -229,25 +274,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
     const int split = (g0 + 1) * g.cpg - ch0;
     const int g1 = (split < 8) ? g0 + 1 : g0;
     float ga[8], be[8];
+    {  // four 16-byte loads, not sixteen scalar ones
+      const f32x4 ga0 = *reinterpret_cast<const f32x4*>(gamma + ch0), ga1 = *reinterpret_cast<const f32x4*>(gamma + ch0 + 4);
+      const f32x4 be0 = *reinterpret_cast<const f32x4*>(beta + ch0), be1 = *reinterpret_cast<const f32x4*>(beta + ch0 + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ga[j] = gamma[ch0 + j];
-      be[j] = beta[ch0 + j];
+      for (int j = 0; j < 4; ++j) {
+        ga[j] = ga0[j];
+        ga[4 + j] = ga1[j];
+        be[j] = be0[j];
+        be[4 + j] = be1[j];
+      }
     }
     float mlo, rlo, mhi, rhi;
     if constexpr (FROM_SUMS && !BWD) {
-      // the statistics pass ran inside the producing GEMM: finish it here (every thread for its two groups;
-      // slab 0 also publishes mean / rstd for the backward)
-      gn_stat_from_sums(g, sums, slots, b, g0, eps, mlo, rlo);
-      mhi = mlo;
-      rhi = rlo;
-      if (g1 != g0) gn_stat_from_sums(g, sums, slots, b, g1, eps, mhi, rhi);
-      if (slab == 0 && ty == 0) {
-        mean_out[b * g.G + g0] = mlo;
-        rstd_out[b * g.G + g0] = rlo;
-        mean_out[b * g.G + g1] = mhi;
-        rstd_out[b * g.G + g1] = rhi;
-      }
+      mlo = s_stat[0][g0];
+      rlo = s_stat[1][g0];
+      mhi = s_stat[0][g1];
+      rhi = s_stat[1][g1];
     } else {
       mlo = mean[b * g.G + g0];
       rlo = rstd[b * g.G + g0];
@@ -255,11 +298,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
       rhi = rstd[b * g.G + g1];
     }
     float c1lo = 0.f, c2lo = 0.f, c1hi = 0.f, c2hi = 0.f;
-    if constexpr (BWD && FROM_SUMS) {  // the statistics pass added its slab sums to the slots: finish them here
-      gn_coef_from_sums(g, sums, slots, b, g0, c1lo, c2lo);
-      c1hi = c1lo;
-      c2hi = c2lo;
-      if (g1 != g0) gn_coef_from_sums(g, sums, slots, b, g1, c1hi, c2hi);
+    if constexpr (BWD && FROM_SUMS) {
+      c1lo = s_stat[0][g0];
+      c2lo = s_stat[1][g0];
+      c1hi = s_stat[0][g1];
+      c2hi = s_stat[1][g1];
     } else if (BWD) {
       c1lo = c1[b * g.G + g0];
       c2lo = c2[b * g.G + g0];
@@ -350,7 +393,7 @@ __global__ __launch_bounds__(512) void gn_small_kernel(int HW, int C, int G, con
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ mean, float* __restrict__ rstd, float eps,
                                                        half_t* __restrict__ out, long long ldo,
-                                                       const half_t* __restrict__ accum, long long ldacc) {
+                                                       const half_t* __restrict__ accum, long long ldacc, double inv_n) {
   __shared__ double red[2][8];
   __shared__ float stat[2];
   __shared__ float sga[128], sbe[128];  // this group's gamma / beta (cpg <= 128)
@@ -433,18 +476,13 @@ __global__ __launch_bounds__(512) void gn_small_kernel(int HW, int C, int G, con
       t0 += red[0][w];
       t1 += red[1][w];
     }
-    const double n = (double)HW * cpg;
     if (!BWD) {
-      const double mu = t0 / n;
-      double var = t1 / n - mu * mu;
-      if (var < 0.0) var = 0.0;
-      stat[0] = (float)mu;
-      stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+      vn_mean_rstd(t0, t1, inv_n, eps, stat[0], stat[1]);
       mean[b * G + gi] = stat[0];
       rstd[b * G + gi] = stat[1];
     } else {
-      stat[0] = (float)(t0 / n);
-      stat[1] = (float)(t1 / n);
+      stat[0] = (float)(t0 * inv_n);
+      stat[1] = (float)(t1 * inv_n);
     }
   }
   __syncthreads();
@@ -529,6 +567,7 @@ int gn_geom(GNGeom& g, int Bn, int HW, int C, int G) {
   }
   g.rps = rps;
   g.nslab = nslab;
+  g.inv_n = 1.0 / ((double)HW * g.cpg);
   return 0;
 }
 
@@ -617,7 +656,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     s += ok[i] ? t : 0.f;
   }
   s = wave_sum(s);
-  const float m = s / (float)C;
+  const float inv_c = __builtin_amdgcn_rcpf((float)C);  // (1 ulp; an IEEE division is ~10 issues on the critical path of every row)
+  const float m = s * inv_c;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
@@ -630,7 +670,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     q += ok[i] ? t : 0.f;
   }
   q = wave_sum(q);
-  const float rs = rsqrtf(q / (float)C + eps);
+  const float rs = rsqrtf(q * inv_c + eps);
   if (lane == 0) {
     if (mean) mean[row] = m;
     if (rstd) rstd[row] = rs;
@@ -691,8 +731,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     s1 += ok[i] ? t1 : 0.f;
     s2 += ok[i] ? t2 : 0.f;
   }
-  s1 = wave_sum(s1) / (float)C;
-  s2 = wave_sum(s2) / (float)C;
+  const float inv_c = __builtin_amdgcn_rcpf((float)C);
+  s1 = wave_sum(s1) * inv_c;
+  s2 = wave_sum(s2) * inv_c;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     if (ok[i]) {
@@ -786,11 +827,11 @@ extern "C" int vneti_groupnorm_fwd(const void* x, long long ldx, void* y, long l
     if (silu)
       hipLaunchKernelGGL((gn_small_kernel<false, true>), dim3(G, Bn), dim3(512), 0, st, HW, C, G, (const half_t*)x, ldx,
                          (const half_t*)nullptr, 0LL, gamma, beta, mean, rstd, eps, (half_t*)y, ldy,
-                         (const half_t*)nullptr, 0LL);
+                         (const half_t*)nullptr, 0LL, g.inv_n);
     else
       hipLaunchKernelGGL((gn_small_kernel<false, false>), dim3(G, Bn), dim3(512), 0, st, HW, C, G, (const half_t*)x, ldx,
                          (const half_t*)nullptr, 0LL, gamma, beta, mean, rstd, eps, (half_t*)y, ldy,
-                         (const half_t*)nullptr, 0LL);
+                         (const half_t*)nullptr, 0LL, g.inv_n);
     return vneti_check_launch("groupnorm_fwd");
   }
   dim3 grid(g.nslab, Bn);
@@ -869,11 +910,11 @@ extern "C" int vneti_groupnorm_bwd(const void* dy, long long lddy, const void* x
     if (silu)
       hipLaunchKernelGGL((gn_small_kernel<true, true>), dim3(G, Bn), dim3(512), 0, st, HW, C, G, (const half_t*)x, ldx,
                          (const half_t*)dy, lddy, gamma, beta, const_cast<float*>(mean), const_cast<float*>(rstd), 0.f,
-                         (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc);
+                         (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc, g.inv_n);
     else
       hipLaunchKernelGGL((gn_small_kernel<true, false>), dim3(G, Bn), dim3(512), 0, st, HW, C, G, (const half_t*)x, ldx,
                          (const half_t*)dy, lddy, gamma, beta, const_cast<float*>(mean), const_cast<float*>(rstd), 0.f,
-                         (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc);
+                         (half_t*)dx, lddx, (const half_t*)dx_accum, ldacc, g.inv_n);
     return vneti_check_launch("groupnorm_bwd");
   }
   dim3 grid(g.nslab, Bn);
