@@ -394,6 +394,12 @@ __global__ __launch_bounds__(512) void gn_small_kernel(int HW, int C, int G, con
                                                        float* __restrict__ mean, float* __restrict__ rstd, float eps,
                                                        half_t* __restrict__ out, long long ldo,
                                                        const half_t* __restrict__ accum, long long ldacc, double inv_n) {
+  // The slice of one (sample, group) is at most 40 KiB forward / 32 KiB backward (gn_use_small), i.e. at most MAXU
+  // half2 pairs per thread: every load of the block is issued up front, the slice stays in registers between the
+  // statistics and the apply step (one trip to memory, no second walk), and the row / column of a pair come from a
+  // float-reciprocal division instead of an integer one.
+  constexpr int MAXU = BWD ? 16 : 20;
+  constexpr int NTH = 512;
   __shared__ double red[2][8];
   __shared__ float stat[2];
   __shared__ float sga[128], sbe[128];  // this group's gamma / beta (cpg <= 128)
@@ -402,9 +408,7 @@ __global__ __launch_bounds__(512) void gn_small_kernel(int HW, int C, int G, con
   const int c0 = gi * cpg;
   const int total = HW * hp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int NTH = blockDim.x;
   typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-  constexpr int U = 8;  // independent 4-byte loads in flight per thread and tensor
   for (int i = threadIdx.x; i < cpg; i += NTH) {
     sga[i] = gamma[c0 + i];
     sbe[i] = beta[c0 + i];
@@ -414,48 +418,54 @@ __global__ __launch_bounds__(512) void gn_small_kernel(int HW, int C, int G, con
     m = mean[b * G + gi];
     rs = rstd[b * G + gi];
   }
-  __syncthreads();
   const half_t* xb = x + (long long)b * HW * ldx + c0;
   const half_t* dyb = BWD ? dy + (long long)b * HW * lddy + c0 : nullptr;
-  // ---- pass 1: FWD (sum, sum of squares); BWD (sum dxh, sum dxh * xhat)
-  float s0 = 0.f, s1 = 0.f;
-  for (int base = threadIdx.x; base < total; base += NTH * U) {
-    half2_t xv[U], dv[U];
-    int cps[U];
+  const half_t* ab = accum ? accum + (long long)b * HW * ldacc + c0 : nullptr;
+  const float rcp_hp = __builtin_amdgcn_rcpf((float)hp);
+  half2_t xv[MAXU], dv[BWD ? MAXU : 1], av[BWD ? MAXU : 1];
+  int rows[MAXU], cps[MAXU];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = base + u * NTH;
-      const int r = p / hp;
-      cps[u] = (p - r * hp) * 2;
-      xv[u] = half2_t{(half_t)0.f, (half_t)0.f};
+  for (int u = 0; u < MAXU; ++u) {
+    const int p = threadIdx.x + u * NTH;
+    int cp;
+    rows[u] = vn_divmod(p, hp, rcp_hp, cp);
+    cps[u] = cp * 2;
+    xv[u] = half2_t{(half_t)0.f, (half_t)0.f};
+    if (BWD) {
       dv[u] = xv[u];
-      if (p < total) {
-        xv[u] = *reinterpret_cast<const half2_t*>(xb + (long long)r * ldx + cps[u]);
-        if (BWD) dv[u] = *reinterpret_cast<const half2_t*>(dyb + (long long)r * lddy + cps[u]);
+      av[u] = xv[u];
+    }
+    if (p < total) {
+      xv[u] = *reinterpret_cast<const half2_t*>(xb + (long long)rows[u] * ldx + cps[u]);
+      if (BWD) {
+        dv[u] = *reinterpret_cast<const half2_t*>(dyb + (long long)rows[u] * lddy + cps[u]);
+        if (ab) av[u] = *reinterpret_cast<const half2_t*>(ab + (long long)rows[u] * ldacc + cps[u]);
       }
     }
+  }
+  __syncthreads();  // sga / sbe
+  // ---- statistics: FWD (sum, sum of squares); BWD (sum dxh, sum dxh * xhat); pairs past the end hold zeros
+  float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (base + u * NTH >= total) break;
-      if (!BWD) {
-        const float v0 = (float)xv[u][0], v1 = (float)xv[u][1];
-        s0 += v0 + v1;
-        s1 += v0 * v0 + v1 * v1;
-      } else {
+  for (int u = 0; u < MAXU; ++u) {
+    if (!BWD) {
+      const float v0 = (float)xv[u][0], v1 = (float)xv[u][1];
+      s0 += v0 + v1;
+      s1 += v0 * v0 + v1 * v1;
+    } else if (threadIdx.x + u * NTH < total) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float ga = sga[cps[u] + j];
-          const float xh = ((float)xv[u][j] - m) * rs;
-          float d = (float)dv[u][j];
-          if (SILU) {
-            const float z = xh * ga + sbe[cps[u] + j];
-            const float sg = vn_sigmoid(z);
-            d *= sg * (1.f + z * (1.f - sg));
-          }
-          const float dxh = d * ga;
-          s0 += dxh;
-          s1 += dxh * xh;
+      for (int j = 0; j < 2; ++j) {
+        const float ga = sga[cps[u] + j];
+        const float xh = ((float)xv[u][j] - m) * rs;
+        float d = (float)dv[u][j];
+        if (SILU) {
+          const float z = xh * ga + sbe[cps[u] + j];
+          const float sg = vn_sigmoid(z);
+          d *= sg * (1.f + z * (1.f - sg));
         }
+        const float dxh = d * ga;
+        s0 += dxh;
+        s1 += dxh * xh;
       }
     }
   }
@@ -487,54 +497,33 @@ __global__ __launch_bounds__(512) void gn_small_kernel(int HW, int C, int G, con
   }
   __syncthreads();
   const float a0 = stat[0], a1 = stat[1];  // FWD: mean, rstd;  BWD: c1, c2
-  // ---- pass 2: apply (x and dy come back from L2)
+  // ---- apply, from the registers
   half_t* ob = out + (long long)b * HW * ldo + c0;
-  const half_t* ab = accum ? accum + (long long)b * HW * ldacc + c0 : nullptr;
-  for (int base = threadIdx.x; base < total; base += NTH * U) {
-    half2_t xv[U], dv[U], av[U];
-    int cps[U], rows[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = base + u * NTH;
-      rows[u] = p / hp;
-      cps[u] = (p - rows[u] * hp) * 2;
-      xv[u] = half2_t{(half_t)0.f, (half_t)0.f};
-      dv[u] = xv[u];
-      av[u] = xv[u];
-      if (p < total) {
-        xv[u] = *reinterpret_cast<const half2_t*>(xb + (long long)rows[u] * ldx + cps[u]);
-        if (BWD) {
-          dv[u] = *reinterpret_cast<const half2_t*>(dyb + (long long)rows[u] * lddy + cps[u]);
-          if (ab) av[u] = *reinterpret_cast<const half2_t*>(ab + (long long)rows[u] * ldacc + cps[u]);
+  for (int u = 0; u < MAXU; ++u) {
+    if (threadIdx.x + u * NTH >= total) break;
+    half2_t ov;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float ga = sga[cps[u] + j], be = sbe[cps[u] + j];
+      if (!BWD) {
+        float z = ((float)xv[u][j] - a0) * a1 * ga + be;
+        if (SILU) z = vn_silu(z);
+        ov[j] = (half_t)z;
+      } else {
+        const float xh = ((float)xv[u][j] - m) * rs;
+        float d = (float)dv[u][j];
+        if (SILU) {
+          const float z = xh * ga + be;
+          const float sg = vn_sigmoid(z);
+          d *= sg * (1.f + z * (1.f - sg));
         }
+        float dx = rs * (d * ga - a0 - xh * a1);
+        if (ab) dx += (float)av[u][j];
+        ov[j] = (half_t)dx;
       }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (base + u * NTH >= total) break;
-      half2_t ov;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float ga = sga[cps[u] + j], be = sbe[cps[u] + j];
-        if (!BWD) {
-          float z = ((float)xv[u][j] - a0) * a1 * ga + be;
-          if (SILU) z = vn_silu(z);
-          ov[j] = (half_t)z;
-        } else {
-          const float xh = ((float)xv[u][j] - m) * rs;
-          float d = (float)dv[u][j];
-          if (SILU) {
-            const float z = xh * ga + be;
-            const float sg = vn_sigmoid(z);
-            d *= sg * (1.f + z * (1.f - sg));
-          }
-          float dx = rs * (d * ga - a0 - xh * a1);
-          if (ab) dx += (float)av[u][j];
-          ov[j] = (half_t)dx;
-        }
-      }
-      *reinterpret_cast<half2_t*>(ob + (long long)rows[u] * ldo + cps[u]) = ov;
-    }
+    *reinterpret_cast<half2_t*>(ob + (long long)rows[u] * ldo + cps[u]) = ov;
   }
 }
 
