@@ -16,7 +16,11 @@ for (B, H, W, Ci, Co) in [(4, 512, 512, 128, 128), (4, 256, 256, 256, 256), (4, 
     conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci)
     gf = 2.0 * B * H * W * Co * 9 * Ci / 1e9
     out = []
-    for h in (1, 5, 6, 7, 8, 9, 10, 13, 16, 17):
+    from view_neti_amd import packing
+    w4 = (torch.randn(Co, Ci, 3, 3) * 0.03).half()
+    for h, ko in ((5, 0), (7, 0), (9, 0), (16, 0), (17, 0), (16, 1), (17, 1), (5, 1), (7, 1)):
+        w = packing.conv3x3_fwd(w4, cm=bool(ko)).to(dev)
+        conv["korder"] = ko
         ts = []
         for _ in range(7):
             cold.fill_(0)
@@ -27,5 +31,5 @@ for (B, H, W, Ci, Co) in [(4, 512, 512, 128, 128), (4, 256, 256, 256, 256), (4, 
             e.record(); e.synchronize()
             ts.append(s.elapsed_time(e) * 1e3)
         t = sorted(ts)[3]
-        out.append(f"h{h} {t:6.1f}us {gf / t * 1e3:4.0f}TF")
+        out.append(f"h{h}{'cm' if ko else ''} {t:6.1f}us {gf / t * 1e3:4.0f}TF")
     print(f"conv {H}x{W} {Ci}->{Co} {gf:6.1f}GF cold+gn: " + " ".join(out), flush=True)

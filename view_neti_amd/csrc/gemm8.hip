@@ -172,8 +172,13 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   {
     int tap = 0, ci0 = 0;
     if constexpr (CONV) {
-      tap = (kt_begin * 64) / g.Ci;
-      ci0 = kt_begin * 64 - tap * g.Ci;
+      if (g.korder) {
+        ci0 = (kt_begin / 9) * 64;
+        tap = kt_begin - (kt_begin / 9) * 9;
+      } else {
+        tap = (kt_begin * 64) / g.Ci;
+        ci0 = kt_begin * 64 - tap * g.Ci;
+      }
     }
     a_tap[0] = a_tap[1] = tap;
     a_ci0[0] = a_ci0[1] = ci0;
@@ -196,10 +201,18 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       const int dx = tap - 3 * dy;
       soff = (dy * g.Wi + dx) * tap_step + a_ci0[h] * 2;
       tapbit = live ? (1u << tap) : 0u;
-      a_ci0[h] += 64;
-      if (a_ci0[h] == g.Ci) {
-        a_ci0[h] = 0;
-        a_tap[h] += 1;
+      if (g.korder) {  // chunk-major K: the nine taps of a 64-channel chunk are consecutive K-tiles (their re-reads of the
+        a_tap[h] += 1;  // same few input rows hit L2 instead of the fabric); costs nothing here, the offsets are linear
+        if (a_tap[h] == 9) {
+          a_tap[h] = 0;
+          a_ci0[h] += 64;
+        }
+      } else {
+        a_ci0[h] += 64;
+        if (a_ci0[h] == g.Ci) {
+          a_ci0[h] = 0;
+          a_tap[h] += 1;
+        }
       }
     }
 #pragma unroll
@@ -709,7 +722,7 @@ inline int epilogue_level8(const GemmArgs& g) {
 // split-K reduce itself.  Returns VNETI_EUNSUP for what this tile does not carry (f32 output, chunk-major conv K order).
 int vneti_launch_gemm8(void* gemm_args, int bn, hipStream_t st) {
   GemmArgs& g = *reinterpret_cast<GemmArgs*>(gemm_args);
-  if (g.out_f32 || (g.conv_mode && (g.korder || g.ups || (g.conv_mode == 2 && g.stride == 2))) ||
+  if (g.out_f32 || (g.conv_mode && (g.ups || (g.conv_mode == 2 && g.stride == 2))) ||
       (g.M >= (1 << 24) && (g.conv_mode || g.rowadd || g.gn_sums)))  // float-reciprocal row arithmetic: rows < 2^24
     return VNETI_EUNSUP;
   g.tiles_m = cdiv(g.M, BM);

@@ -909,7 +909,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   VN_REQUIRE(cfg >= 1 && cfg <= kMaxTile, "gemm: unknown tile_hint %d", d->tile_hint);
   // the 8-phase tile: LDS-DMA only; convolutions whose gather offset is linear in the tap (no fused upsample, no
   // stride-2 transposed gather), tap-major K order
-  if ((cfg == 16 || cfg == 17) && (!dma || (d->conv_mode && (d->conv_korder || d->ups || (d->conv_mode == 2 && d->stride == 2))) ||
+  if ((cfg == 16 || cfg == 17) && (!dma || (d->conv_mode && (d->ups || (d->conv_mode == 2 && d->stride == 2))) ||
                     (d->M >= (1 << 24) && (d->conv_mode || d->rowadd || d->gn_sums)))) cfg = cfg == 16 ? 5 : 7;
   if ((cfg == 5 || cfg == 16) && f32) cfg = 4;
   if (cfg == 17 && f32) cfg = 7;  // the 256x256 tiles' f32 epilogue staging would not fit in LDS
