@@ -318,3 +318,57 @@ def test_coach_reference_default_mapper_config_trains(tmp_path):
     m = lookup[tok_id]
     assert m.legacy and torch.equal(m.encoder.w, coach.mapper_object_lookup[tok_id].encoder.w)
     assert torch.equal(flatten_mapper_state(m.mapper_state()), eng.params.cpu())
+
+
+M1_YAML = """
+learnable_mode: 1
+log: {{exp_name: m1, exp_dir: {out}, save_steps: 3}}
+data: {{train_data_dir: data/dtu/Rectified/scan65, placeholder_object_token: <object>, fixed_object_token_or_path: statue,
+       dataloader_num_workers: 0, camera_representation: dtu-12d, dtu_subset: 3, dtu_lighting: 3, dtu_preprocess_key: 0,
+       augmentation_key: 0, resolution: 64}}
+model: {{arch_mlp_hidden_dims: 64, use_nested_dropout: False, word_embedding_dim: 128, arch_view_net: 15,
+        arch_view_disable_tl: False, pe_sigma_exp_key: 2, output_bypass_alpha_view: 5}}
+eval: {{validation_steps: 1000}}
+optim: {{max_train_steps: 4, train_batch_size: 2, gradient_accumulation_steps: 1, mixed_precision: fp16}}
+"""
+
+
+def test_coach_mode1_view_mapper_only(tmp_path, monkeypatch):
+    """learnable_mode 1 (training/coach.py:493,553-584; dataset.py:654-668): only the view mapper trains, the object is a
+    vocabulary word — captions "<view_x>. A photo of a statue", no object placeholder in the batch, no object checkpoint."""
+    from view_neti_amd.compat import config as C
+    from view_neti_amd.compat.checkpoint_handler import CheckpointHandler
+    from view_neti_amd.compat.coach import Coach
+    from view_neti_amd.compat.dataset import TextualInversionDataset
+    from view_neti_amd.engine.text import flatten_mapper_state
+    monkeypatch.chdir(tmp_path)
+    cal = tmp_path / "data" / "dtu" / "Calibration" / "cal18"
+    cal.mkdir(parents=True)
+    rng = np.random.RandomState(2)
+    mats = rng.randn(49, 3, 4) * np.array([[1e3, 1e3, 1e3, 1e5]])
+    for i in range(49):
+        np.savetxt(cal / f"pos_{i + 1:03d}.txt", mats[i])
+    d = tmp_path / "data" / "dtu" / "Rectified" / "scan65"
+    d.mkdir(parents=True)
+    for c in range(49):
+        Image.fromarray(rng.randint(0, 255, (1200, 1600, 3), dtype=np.uint8)).save(
+            d / TextualInversionDataset.dtu_cam_and_lighting_to_fname(c, "3"))
+    y = tmp_path / "m1.yaml"
+    y.write_text(M1_YAML.format(out=str(tmp_path / "out")))
+    cfg = C.parse(C.RunConfig, ["--config_path", str(y)])
+    cfg.log.exp_dir = cfg.log.exp_dir / cfg.log.exp_name
+    cfg.log.logging_dir = cfg.log.exp_dir / cfg.log.logging_dir
+    torch.manual_seed(cfg.seed)
+    coach = Coach(cfg)
+    eng = coach.engine
+    assert coach.mapper_object_lookup is None and coach.mapper_view is not None
+    ex = coach.train_dataset[0]
+    assert int(ex["input_ids_placeholder_object"]) == -1 and ex["text"].endswith(". A photo of a statue")
+    v0 = eng.view_params_flat().clone()
+    coach.train()
+    assert eng.opt_step.item() == 4 and torch.isfinite(eng.params).all()
+    assert not torch.equal(v0, eng.view_params_flat()), "the view mapper must train"
+    out = cfg.log.exp_dir
+    assert (out / "mapper-final_view.pt").exists() and not (out / "mapper-final_object.pt").exists()
+    _, view = CheckpointHandler.load_mapper(out / "mapper-final_view.pt", "view")
+    assert torch.equal(flatten_mapper_state(view.mapper_state()), eng.view_params_flat().cpu())

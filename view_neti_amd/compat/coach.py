@@ -22,6 +22,7 @@ from __future__ import annotations
 import logging
 import sys
 import time
+from pathlib import Path
 from typing import Dict, Optional
 
 import torch
@@ -85,7 +86,8 @@ class Coach:
         self.mapper_object_lookup, self.mapper_view = self._init_neti_mappers()
         # engine slot k <-> k-th placeholder object token (mapper_object_lookup, coach.py:505-552)
         self.object_slot = {tid: k for k, tid in enumerate(self.placeholder_object_token_ids)}
-        objs = [self.mapper_object_lookup[tid] for tid in self.placeholder_object_token_ids]
+        objs = [self.mapper_object_lookup[tid] for tid in self.placeholder_object_token_ids] \
+            if self.mapper_object_lookup is not None else [self._standin_object]
         first = objs[0]
         m = cfg.model
         bs = cfg.optim.train_batch_size
@@ -112,8 +114,10 @@ class Coach:
             **first.engine_encoder_kwargs(), **kw)
         self.engine.set_lr(self.lr_schedule.lr(0))
         self.validator = None
+        if cfg.learnable_mode == 1 and cfg.eval.validation_prompts is not None:
+            self.log("learnable_mode 1: the validation grids (which sample with an object mapper) are skipped")
         if cfg.eval.validation_prompts is not None and cfg.eval.validation_steps <= cfg.optim.max_train_steps \
-                and self.rank == 0:
+                and self.rank == 0 and cfg.learnable_mode != 1:
             from .sd_weights import load_vae_decoder_weights
             from .validate import ValidationHandler
             dec_w, _ = load_vae_decoder_weights(self.sd, str(cfg.model.pretrained_model_name_or_path), device,
@@ -247,9 +251,10 @@ class Coach:
             # AttributeError in the reference itself (probed with the real modules)
             raise NotImplementedError("original_ti: the reference's own path raises AttributeError "
                                       "(net_clip_text_embedding.py:80 on the tensor neti_mapper.py:183-192 returns)")
-        if cfg.learnable_mode == 1:
-            raise NotImplementedError("learnable_mode 1 (view mapper only, fixed object word) is not built: the engine "
-                                      "always trains an object bucket; use mode 2, or mode 5 with a pretrained view mapper")
+        if cfg.learnable_mode == 1 and Path(str(cfg.data.fixed_object_token_or_path)).exists():
+            # coach.py:554-558: a pretrained object mapper kept frozen beside the trained view mapper
+            raise NotImplementedError("learnable_mode 1 with a pretrained object mapper (fixed_object_token_or_path is a "
+                                      "file): the engine has no frozen object bucket; a vocabulary word works")
         if (m.bypass_unconstrained_object and not m.output_bypass_object) or \
                 (m.bypass_unconstrained_view and not m.output_bypass_view):
             raise ValueError("bypass_unconstrained needs output_bypass (neti_mapper.py:130-132)")
@@ -264,7 +269,7 @@ class Coach:
                                           nested_dropout_prob=m.nested_dropout_prob, arch_view_net=m.arch_view_net,
                                           num_pe_time_anchors=m.num_pe_time_anchors)
         view = None
-        if cfg.learnable_mode in (2, 3):
+        if cfg.learnable_mode in (1, 2, 3):
             ds = self.train_dataset
             cams = torch.stack(list(ds.lookup_camidx_to_cam_params.values()))
             view = NeTIMapper("view", m.word_embedding_dim, 64, m.target_norm_view, m.pe_sigmas, m.output_bypass_view,
@@ -276,6 +281,16 @@ class Coach:
             cams = torch.stack(list(ds.lookup_camidx_to_cam_params.values()))
             _, view = CheckpointHandler.load_mapper(m.pretrained_view_mapper, "view", cam_mins=cams.min(0).values.flatten(),
                                                     cam_maxs=cams.max(0).values.flatten())
+        if cfg.learnable_mode == 1:
+            # view mapper only; the object is a plain vocabulary word (dataset.py:654-668: no placeholder id in the batch,
+            # mapper_object_lookup stays None, coach.py:493,508).  The engine's bucket layout wants an object segment: it
+            # gets a stand-in mapper that no prompt ever reaches (placeholder -1 never matches a position) and that is
+            # neither registered nor saved.
+            self._standin_object = NeTIMapper("object", m.word_embedding_dim, m.arch_mlp_hidden_dims, m.target_norm_object,
+                                              m.pe_sigmas, m.output_bypass_object, m.bypass_unconstrained_object,
+                                              m.output_bypass_alpha_object, None, arch_view_net=m.arch_view_net,
+                                              num_pe_time_anchors=m.num_pe_time_anchors)
+            return None, view
         if cfg.learnable_mode != 3 and len(lookup) != 1:
             raise ValueError("only learnable_mode 3 trains more than one object token (dataset.py:612)")
         return lookup, view
@@ -334,7 +349,7 @@ class Coach:
                     raise ValueError("a batch must hold a single object token (net_clip_text_embedding.py:67-68)")
                 eng.set_batch(self._pixels(batch), batch["input_ids"], ids_obj, batch["input_ids_placeholder_view"],
                               self._view_params(batch["input_ids_placeholder_view"]),
-                              object_index=self.object_slot[int(ids_obj[0])])
+                              object_index=self.object_slot.get(int(ids_obj[0]), 0))  # (-1 in mode 1: no object mapper)
                 if not captured:
                     eng.capture()
                     captured = True
