@@ -83,6 +83,32 @@ for f in launches:
     d["fs"].append(f)
     if c:
         d["flops"] += c[1]; d["bytes"] += c[2]
+if os.environ.get("PER_LAUNCH"):
+    # every HBM-bound launch by itself (events around each one, in schedule order), grouped by (class, bytes)
+    import collections
+    per = collections.OrderedDict()
+    hbm = {id(f): (name, cost(f)) for name, d in classes.items() if not d["flops"] for f in d["fs"]}
+    for rep in range(3):
+        evs = []
+        for f in launches:
+            if id(f) in hbm:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); f(); e.record(); evs.append((f, s, e))
+            else:
+                f()
+        torch.cuda.synchronize()
+        if rep:
+            for f, s, e in evs:
+                name, c = hbm[id(f)]
+                nb = c[2] if c else 0.0
+                fn = getattr(getattr(f, "func", f), "__name__", "?")
+                k = (name, fn, int(nb))
+                a = per.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += s.elapsed_time(e) * 1e3
+    print("class | fn | MB | launches/step | us each | TB/s | ms/step")
+    for (name, fn, nb), (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        n2 = n / 2; us = t / n
+        print(f"{name[:38]:38s} {fn[:22]:22s} {nb/1e6:8.2f} MB x{n2:5.1f} {us:7.1f} us {nb/us/1e6 if us else 0:6.2f} TB/s {t/2/1e3:6.3f} ms")
+    sys.exit(0)
 # time: replay the whole list in order, recording events only around the launches of one class at a time
 out = {}
 for name, d in classes.items():

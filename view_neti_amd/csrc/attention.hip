@@ -55,6 +55,17 @@ struct AttnArgs {
 // raw v_exp_f32: the libm exp2 adds a 5-instruction denormal-range fix-up per element, which made
 // the softmax the bottleneck; flushing results below 2^-126 to zero is harmless here.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// two f32 lanes per VALU instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): the softmax element work is what these
+// kernels spend their VALU cycles on, and the compiler does not pair the score scaling by itself.  Same roundings as the
+// scalar forms (one fused multiply-add; a subtract and a multiply).
+// tools/lab/attn_lab.py builds variants of attn_fwd_kernel with pieces removed (results are garbage) to see how the MFMA,
+// VALU, LDS and staging parts add up on the chip: bit 0 no softmax math, 1 no MFMAs, 2 no fragment reads from LDS,
+// 3 no staging (global loads / LDS writes), 4 no per-tile barrier, 5 no max pass.  0 in the product build.
+#ifndef VN_ATTN_LAB
+#define VN_ATTN_LAB 0
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // online-softmax rescale threshold (natural-log units, expressed in log2 units at the use site):
 // the running max is only advanced when some row's max grew by more than this, so in steady state the
@@ -94,14 +105,14 @@ __device__ __forceinline__ half8 load_tr(const char* tile, int row_bytes, int d0
 // ============================================================================================
 // forward
 // ============================================================================================
-template <int D>
+template <int D, int QW>
 // min 2 blocks/CU caps the register budget at 256, which makes the compiler keep MFMA accumulators in
 // arch VGPRs (no v_accvgpr copies around the softmax VALU work)
-__global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (D <= 40 && QW == 1 ? 4 : 2)) void attn_fwd_kernel(AttnArgs a) {
   using C = Cfg<D>;
   // each wave owns QW independent 32-query sub-tiles: K/V fragments are read from LDS once and
-  // used QW times, and the two softmax/MFMA dependency chains interleave inside the wave
-  constexpr int QW = 1;  // 2 sub-tiles per wave measured slower (occupancy 1 wave/SIMD)
+  // used QW times, and the two softmax/MFMA dependency chains interleave inside the wave.  One MFMA per fragment read
+  // (QW = 1) sits exactly on the LDS roofline (1 KB per 32x32x16 MFMA = 128 B/clk/CU at the MFMA rate).
   // when D is padded up to a multiple of 32, column D of the V tile is set to ones so the PV MFMA
   // accumulates the softmax denominator for free (it rescales with O as well)
   constexpr bool ONES = C::DB * 32 > D;
@@ -197,8 +208,9 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
   }
   commit(0);
   __syncthreads();
+  constexpr int LAB = VN_ATTN_LAB;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) issue(kt + 1);
+    if (!(LAB & 8) && kt + 1 < nkt) issue(kt + 1);
     const int key0 = kt * 64;
     const char* Ks = smem + (kt & 1) * STAGE;
     const char* Vs = Ks + KS_BYTES;
@@ -214,11 +226,13 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
     for (int aa = 0; aa < 2; ++aa) {
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        half8 kf = as_half8(
+        half8 kf = (LAB & 4) ? qf[0][ks] : as_half8(
             *reinterpret_cast<const u32x4*>(Ks + (aa * 32 + l31) * C::ROW + (ks * 2 + h2) * 16));
 #pragma unroll
-        for (int u = 0; u < QW; ++u)
-          s[u][aa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][ks], s[u][aa], 0, 0, 0);
+        for (int u = 0; u < QW; ++u) {
+          if constexpr (LAB & 2) asm volatile("" : "+v"(s[u][aa]) : "v"(kf));
+          else s[u][aa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][ks], s[u][aa], 0, 0, 0);
+        }
       }
     }
     if ((key0 + 64 > a.Nk) || a.causal) {  // wave-uniform: only the tail / diagonal tiles pay for masking
@@ -239,8 +253,8 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][aa][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][aa][(LAB & 32) ? 0 : r]);
+      if (!(LAB & 32)) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       if (!__all((mx - m[u]) * c <= RESCALE_THR_LOG2)) {
         // some row's max grew a lot (always true on the first tile): advance the running max and
         // rescale everything accumulated so far, exactly once
@@ -259,10 +273,13 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float p = fast_exp2(s[u][aa][r] * c - mc);
-          s[u][aa][r] = p;
-          if constexpr (!ONES) psum += p;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 t = (LAB & 1) ? f32x2{s[u][aa][r], s[u][aa][r + 1]}
+                                    : pk_fma(f32x2{s[u][aa][r], s[u][aa][r + 1]}, f32x2{c, c}, f32x2{-mc, -mc});
+          const float p0 = (LAB & 1) ? t.x : fast_exp2(t.x), p1 = (LAB & 1) ? t.y : fast_exp2(t.y);
+          s[u][aa][r] = p0;
+          s[u][aa][r + 1] = p1;
+          if constexpr (!ONES) psum += p0 + p1;
         }
       }
       if constexpr (!ONES) l[u] += psum;
@@ -277,15 +294,17 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 2)) void attn_fwd_kernel(AttnAr
         for (int u = 0; u < QW; ++u) pf[u] = cvt8(s[u][aa], j);
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
-          half8 vf = load_tr(Vs, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
+          half8 vf = (LAB & 4) ? qf[0][0] : load_tr(Vs, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
 #pragma unroll
-          for (int u = 0; u < QW; ++u)
-            o[u][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[u][db], 0, 0, 0);
+          for (int u = 0; u < QW; ++u) {
+            if constexpr (LAB & 2) asm volatile("" : "+v"(o[u][db]) : "v"(vf), "v"(pf[u]));
+            else o[u][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[u][db], 0, 0, 0);
+          }
         }
       }
     }
-    if (kt + 1 < nkt) commit((kt + 1) & 1);
-    __syncthreads();
+    if (!(LAB & 8) && kt + 1 < nkt) commit((kt + 1) & 1);
+    if (!(LAB & 16)) __syncthreads();
   }
 
 #pragma unroll
@@ -477,7 +496,13 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dq_kernel(AttnAr
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * c - lse2) * (dp[r] - dlt);
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{c, c}, f32x2{-lse2, -lse2});
+        const f32x2 g = f32x2{dp[r], dp[r + 1]} - f32x2{dlt, dlt};
+        const f32x2 ds = f32x2{fast_exp2(t.x), fast_exp2(t.y)} * g;
+        s[r] = ds.x;
+        s[r + 1] = ds.y;
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         half8 pf = cvt8(s, j);
@@ -651,15 +676,20 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnA
         f32x4 l4 = *reinterpret_cast<const f32x4*>(&lses[hq * 32 + 8 * qd + 4 * h2]);
         f32x4 d4 = *reinterpret_cast<const f32x4*>(&dels[hq * 32 + 8 * qd + 4 * h2]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; e += 2) {
           const int r = 4 * qd + e;
-          float p = fast_exp2(s[r] * c - l4[e]);
+          const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{c, c}, -f32x2{l4[e], l4[e + 1]});
+          f32x2 p = f32x2{fast_exp2(t.x), fast_exp2(t.y)};
           if (a.causal) {
             int qq = q0 + hq * 32 + 8 * qd + 4 * h2 + e;
-            if (key > qq) p = 0.f;
+            if (key > qq) p.x = 0.f;
+            if (key > qq + 1) p.y = 0.f;
           }
-          s[r] = p;
-          dp[r] = p * (dp[r] - d4[e]);
+          const f32x2 ds = p * (f32x2{dp[r], dp[r + 1]} - f32x2{d4[e], d4[e + 1]});
+          s[r] = p.x;
+          s[r + 1] = p.y;
+          dp[r] = ds.x;
+          dp[r + 1] = ds.y;
         }
       }
 #pragma unroll
@@ -757,6 +787,14 @@ int check_common(int Bn, int H, int Nq, int Nk, int D) {
     default: hipLaunchKernelGGL((KERNEL<160>), grid, dim3(256), 0, st, args); break;         \
   }
 
+#define DISPATCH_D1(KERNEL, grid, st, args)                                                     \
+  switch (args.D) {                                                                             \
+    case 40: hipLaunchKernelGGL((KERNEL<40, 1>), grid, dim3(256), 0, st, args); break;          \
+    case 64: hipLaunchKernelGGL((KERNEL<64, 1>), grid, dim3(256), 0, st, args); break;          \
+    case 80: hipLaunchKernelGGL((KERNEL<80, 1>), grid, dim3(256), 0, st, args); break;          \
+    default: hipLaunchKernelGGL((KERNEL<160, 1>), grid, dim3(256), 0, st, args); break;         \
+  }
+
 }  // namespace
 
 extern "C" int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long long ldk, const void* V,
@@ -784,9 +822,14 @@ extern "C" int vneti_attn_fwd(const void* Q, long long ldq, const void* K, long 
   a.D = D;
   a.scale = scale;
   a.causal = causal;
-  dim3 grid(cdiv(Nq, 128), H, Bn);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_D(attn_fwd_kernel, grid, st, a);
+  static const int qw_min = getenv("VNETI_ATTN_QW2_MIN_N") ? atoi(getenv("VNETI_ATTN_QW2_MIN_N")) : 4096;
+  if (D == 40 && Nq >= qw_min) {
+    hipLaunchKernelGGL((attn_fwd_kernel<40, 2>), dim3(cdiv(Nq, 256), H, Bn), dim3(256), 0, st, a);
+    return vneti_check_launch("attn_fwd");
+  }
+  dim3 grid(cdiv(Nq, 128), H, Bn);
+  DISPATCH_D1(attn_fwd_kernel, grid, st, a);
   return vneti_check_launch("attn_fwd");
 }
 

@@ -117,15 +117,30 @@ __device__ __forceinline__ void vn_fx_add2(vn_u64* e, float s, float q) {
   atomicAdd(e + 3, l);
 }
 
+// Wave-wide all-reduce without the LDS crossbar: rotations inside the four 16-lane DPP rows (row_ror:8/4/2/1, one VALU
+// instruction each), then the four row results through v_readlane.  __shfl_xor is a ds_bpermute per step — six dependent
+// LDS round trips — and these reductions sit on the critical path of the one-row-per-wave kernels (LayerNorm, the text
+// path).  All 64 lanes must be active (every caller reduces with full waves).
+template <int N>
+__device__ __forceinline__ float vn_row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float vn_readlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += vn_row_ror<8>(v);
+  v += vn_row_ror<4>(v);
+  v += vn_row_ror<2>(v);
+  v += vn_row_ror<1>(v);
+  return (vn_readlane(v, 0) + vn_readlane(v, 16)) + (vn_readlane(v, 32) + vn_readlane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, vn_row_ror<8>(v));
+  v = fmaxf(v, vn_row_ror<4>(v));
+  v = fmaxf(v, vn_row_ror<2>(v));
+  v = fmaxf(v, vn_row_ror<1>(v));
+  return fmaxf(fmaxf(vn_readlane(v, 0), vn_readlane(v, 16)), fmaxf(vn_readlane(v, 32), vn_readlane(v, 48)));
 }
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }

@@ -25,17 +25,122 @@ struct MapperParams {
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }
 
+// One block of MT threads per mapper row r = (layer, sample).  The weights are the only sizeable operand (0.79 MB for the
+// 1536 x 128 output layer) and every row's block reads all of them out of L2, so the row kernels are latency problems:
+// 16 waves per block, every weight read coalesced along the contiguous index (16-byte loads when the bucket allows: VEC).
+constexpr int MT = 1024;
+
+// all-reduce over the 16 lanes of a DPP row with rotations (four VALU instructions, no LDS crossbar)
+__device__ __forceinline__ float group16_sum(float s) {
+  s += vn_row_ror<8>(s);
+  s += vn_row_ror<4>(s);
+  s += vn_row_ror<2>(s);
+  s += vn_row_ror<1>(s);
+  return s;
+}
+
+// sum over the block of one float per thread; `red` holds MT / 64 floats
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();  // red may still be read from an earlier call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT / 64; ++i) t += red[i];
+  return t;
+}
+
+// emit(o, sum_i W[o][i] x[i]) for o < NO (W row-major [NO][NI], x in LDS): 16 lanes per output row, coalesced along i,
+// four rows per group and pass so that four L2 round trips are in flight (a pass is load -> dot -> reduce, one chain);
+// emit runs in the first lane of the row's group.
+template <bool VEC, class F>
+__device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* x, int NO, int NI, F&& emit) {
+  constexpr int U = 4, ROWS = MT / 16;
+  const int g = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (int o0 = 0; o0 < NO; o0 += U * ROWS) {
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int o = o0 + u * ROWS + grp;
+      s[u] = 0.f;
+      if (o < NO) {
+        const float* wr = W + (long long)o * NI;
+        if constexpr (VEC) {
+          for (int i = g * 4; i < NI; i += 64) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + i);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+            s[u] += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+          }
+        } else {
+          for (int i = g; i < NI; i += 16) s[u] += wr[i] * x[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int o = o0 + u * ROWS + grp;
+      const float t = group16_sum(s[u]);
+      if (g == 0 && o < NO) emit(o, t);
+    }
+  }
+}
+
+// out[i] = sum_o W[o][i] x[o] for i < NI (the transposed product; W row-major [NO][NI], x in LDS, out in LDS): the threads
+// split into partitions over o, each reading whole rows coalesced along i; `part` holds MT * 4 floats.  Ends with a barrier.
+template <bool VEC>
+__device__ __forceinline__ void matvec_cols(const float* __restrict__ W, const float* x, int NO, int NI, float* part,
+                                            float* out) {
+  const int tid = threadIdx.x;
+  if constexpr (VEC) {
+    const int nq = NI / 4, q = tid % nq, p = tid / nq, np = MT / nq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (p < np)
+      for (int o = p; o < NO; o += np) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long long)o * NI + q * 4);
+        const float xv = x[o];
+        acc[0] += w[0] * xv;
+        acc[1] += w[1] * xv;
+        acc[2] += w[2] * xv;
+        acc[3] += w[3] * xv;
+      }
+    if (p < np) *reinterpret_cast<f32x4*>(part + (p * nq + q) * 4) = acc;
+    __syncthreads();
+    if (tid < NI) {
+      float t = 0.f;
+      for (int k = 0; k < np; ++k) t += part[k * NI + tid];
+      out[tid] = t;
+    }
+  } else {
+    const int j = tid % NI, p = tid / NI, np = MT / NI;
+    float acc = 0.f;
+    if (p < np)
+      for (int o = p; o < NO; o += np) acc += W[(long long)o * NI + j] * x[o];
+    if (p < np) part[p * NI + j] = acc;
+    __syncthreads();
+    if (tid < NI) {
+      float t = 0.f;
+      for (int k = 0; k < np; ++k) t += part[k * NI + tid];
+      out[tid] = t;
+    }
+  }
+  __syncthreads();
+}
+
 __device__ void block_layernorm(float* z, const float* gamma, const float* beta, float* xh, float* y, int hd,
                                 float* stat) {
-  // z[hd] in LDS -> xh (normalised), y = xh*gamma+beta; stat[0]=rstd.  eps = 1e-5 (nn.LayerNorm default)
-  if (threadIdx.x == 0) {
+  // z[hd] in LDS -> xh (normalised), y = xh*gamma+beta; stat[1]=rstd.  eps = 1e-5 (nn.LayerNorm default)
+  if (threadIdx.x < 64) {
     float m = 0.f;
-    for (int i = 0; i < hd; ++i) m += z[i];
-    m /= hd;
+    for (int i = threadIdx.x; i < hd; i += 64) m += z[i];
+    m = wave_sum(m) / hd;
     float v = 0.f;
-    for (int i = 0; i < hd; ++i) v += (z[i] - m) * (z[i] - m);
-    stat[0] = m;
-    stat[1] = rsqrtf(v / hd + 1e-5f);
+    for (int i = threadIdx.x; i < hd; i += 64) v += (z[i] - m) * (z[i] - m);
+    v = wave_sum(v);
+    if (threadIdx.x == 0) {
+      stat[0] = m;
+      stat[1] = rsqrtf(v / hd + 1e-5f);
+    }
   }
   __syncthreads();
   if ((int)threadIdx.x < hd) {
@@ -46,19 +151,20 @@ __device__ void block_layernorm(float* z, const float* gamma, const float* beta,
   __syncthreads();
 }
 
-// one block (256 threads) per mapper row r = (layer, sample)
-__global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const float* __restrict__ params,
-                                                         const int* __restrict__ slot, long long slot_stride,
-                                                         const float* __restrict__ data, int nfeat,
-                                                         const float* __restrict__ w_enc,
-                                                         const float* __restrict__ hmask, float norm_scale,
-                                                         float* __restrict__ word, float* __restrict__ bypass,
-                                                         float* __restrict__ save,
-                                                         const float* __restrict__ enc_in) {
-  __shared__ float enc[MAXH], z[MAXH], xh[MAXH], y[MAXH], a[MAXH], stat[2], red[4];
+template <bool VEC>
+__global__ __launch_bounds__(MT) void mapper_fwd_kernel(MapperParams mp, const float* __restrict__ params,
+                                                        const int* __restrict__ slot, long long slot_stride,
+                                                        const float* __restrict__ data, int nfeat,
+                                                        const float* __restrict__ w_enc,
+                                                        const float* __restrict__ hmask, float norm_scale,
+                                                        float* __restrict__ word, float* __restrict__ bypass,
+                                                        float* __restrict__ save,
+                                                        const float* __restrict__ enc_in) {
+  __shared__ __attribute__((aligned(16))) float outs[2048 + 64], enc[MAXH], z[MAXH], xh[MAXH], y[MAXH], a[MAXH];
+  __shared__ float stat[2], red[MT / 64];
   const int r = blockIdx.x, tid = threadIdx.x;
   if (slot) params += (long long)slot[0] * slot_stride;  // which mapper of a multi-mapper bucket (device-side)
-  const int E = mp.E, hd = mp.hd, D = mp.D;
+  const int E = mp.E, hd = mp.hd, D = mp.D, OD = mp.OD;
   // per-row save area: enc[E] | xh1[hd] | a1[hd] | xh2[hd] | a2m[hd] | rstd1, rstd2, wnorm, pad
   float* sv = save + (long long)r * (E + 4 * hd + 4);
   if (enc_in) {  // legacy mapper: the first-layer input is the output of its trainable input_layer (computed upstream)
@@ -71,12 +177,7 @@ __global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const 
   }
   __syncthreads();
   if (tid < E) sv[tid] = enc[tid];
-  if (tid < hd) {
-    float s = params[mp.b0 + tid];
-    const float* wr = params + mp.w0 + tid * E;
-    for (int i = 0; i < E; ++i) s += wr[i] * enc[i];
-    z[tid] = s;
-  }
+  matvec_rows<VEC>(params + mp.w0, enc, hd, E, [&](int o, float s) { z[o] = s + params[mp.b0 + o]; });
   __syncthreads();
   block_layernorm(z, params + mp.g1, params + mp.be1, xh, y, hd, stat);
   if (tid < hd) {
@@ -86,12 +187,7 @@ __global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const 
   }
   if (tid == 0) sv[E + 4 * hd] = stat[1];
   __syncthreads();
-  if (tid < hd) {
-    float s = params[mp.b3 + tid];
-    const float* wr = params + mp.w3 + tid * hd;
-    for (int i = 0; i < hd; ++i) s += wr[i] * a[i];
-    z[tid] = s;
-  }
+  matvec_rows<VEC>(params + mp.w3, a, hd, hd, [&](int o, float s) { z[o] = s + params[mp.b3 + o]; });
   __syncthreads();
   block_layernorm(z, params + mp.g2, params + mp.be2, xh, y, hd, stat);
   if (tid < hd) {
@@ -103,43 +199,37 @@ __global__ __launch_bounds__(256) void mapper_fwd_kernel(MapperParams mp, const 
   }
   if (tid == 0) sv[E + 4 * hd + 1] = stat[1];
   __syncthreads();
-  // output layer
+  // output layer: [word | bypass] rows of net.output_layer
   float sq = 0.f;
-  for (int o = tid; o < mp.OD; o += 256) {
-    float s = params[mp.bo + o];
-    const float* wr = params + mp.wo + (long long)o * hd;
-    for (int i = 0; i < hd; ++i) s += wr[i] * a[i];
-    if (o < D) {
-      word[(long long)r * D + o] = s;
-      sq += s * s;
-    } else {
-      bypass[(long long)r * D + (o - D)] = s;
-    }
-  }
-  sq = wave_sum(sq);
-  if ((tid & 63) == 0) red[tid >> 6] = sq;
-  __syncthreads();
-  const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  matvec_rows<VEC>(params + mp.wo, a, OD, hd, [&](int o, float s) {
+    s += params[mp.bo + o];
+    outs[o] = s;
+    if (o < D) sq += s * s;
+  });
+  const float nrm = sqrtf(block_sum(sq, red));  // (its barriers also publish outs)
   if (tid == 0) sv[E + 4 * hd + 2] = nrm;
-  if (norm_scale > 0.f) {
-    const float f = norm_scale / fmaxf(nrm, 1e-12f);  // F.normalize(eps=1e-12) * norm_scale
-    for (int o = tid; o < D; o += 256) word[(long long)r * D + o] *= f;
+  const float f = norm_scale > 0.f ? norm_scale / fmaxf(nrm, 1e-12f) : 1.f;  // F.normalize(eps=1e-12) * norm_scale
+  for (int o = tid; o < OD; o += MT) {
+    if (o < D) word[(long long)r * D + o] = outs[o] * f;
+    else bypass[(long long)r * D + (o - D)] = outs[o];
   }
 }
 
 // backward stage 1: per row, from (d_word, d_bypass) down to the pre-LayerNorm gradients.
 // rowgrads layout per row: dout[OD] | dz2[hd] | dy2[hd] | dz1[hd] | dy1[hd]
-__global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, const float* __restrict__ params,
-                                                              const int* __restrict__ slot, long long slot_stride,
-                                                              const float* __restrict__ hmask, float norm_scale,
-                                                              const float* __restrict__ word,
-                                                              const float* __restrict__ dword_src,
-                                                              const int* __restrict__ dword_rows, long long ld_src,
-                                                              const float* __restrict__ dbypass,
-                                                              const float* __restrict__ save,
-                                                              float* __restrict__ rowgrads,
-                                                              float* __restrict__ denc) {
-  __shared__ float dout[2048 + 64], part[4][MAXH], dz[MAXH], da[MAXH], red[4], st[2];
+template <bool VEC>
+__global__ __launch_bounds__(MT) void mapper_bwd_rows_kernel(MapperParams mp, const float* __restrict__ params,
+                                                             const int* __restrict__ slot, long long slot_stride,
+                                                             const float* __restrict__ hmask, float norm_scale,
+                                                             const float* __restrict__ word,
+                                                             const float* __restrict__ dword_src,
+                                                             const int* __restrict__ dword_rows, long long ld_src,
+                                                             const float* __restrict__ dbypass,
+                                                             const float* __restrict__ save,
+                                                             float* __restrict__ rowgrads,
+                                                             float* __restrict__ denc) {
+  __shared__ __attribute__((aligned(16))) float dout[2048 + 64], part[MT * 4], dz[MAXH], da[MAXH], t2[MAXH];
+  __shared__ float red[MT / 64], st[2];
   const int r = blockIdx.x, tid = threadIdx.x;
   if (slot) params += (long long)slot[0] * slot_stride;
   const int E = mp.E, hd = mp.hd, D = mp.D, OD = mp.OD;
@@ -149,13 +239,10 @@ __global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, c
   // ---- through F.normalize * norm_scale ----
   float dot = 0.f;
   if (norm_scale > 0.f)
-    for (int o = tid; o < D; o += 256) dot += (word[(long long)r * D + o] / norm_scale) * dw[o];
-  dot = wave_sum(dot);
-  if ((tid & 63) == 0) red[tid >> 6] = dot;
-  __syncthreads();
-  dot = red[0] + red[1] + red[2] + red[3];
+    for (int o = tid; o < D; o += MT) dot += (word[(long long)r * D + o] / norm_scale) * dw[o];
+  dot = block_sum(dot, red);
   const float nrm = fmaxf(sv[E + 4 * hd + 2], 1e-12f);
-  for (int o = tid; o < OD; o += 256) {
+  for (int o = tid; o < OD; o += MT) {
     float g;
     if (o < D) {
       g = dw[o];
@@ -167,64 +254,54 @@ __global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, c
     rg[o] = g;
   }
   __syncthreads();
-  // ---- da2m[j] = sum_o Wout[o][j] dout[o] ----
-  {
-    const int j = tid % hd, p = tid / hd, np = (256 / hd) < 4 ? (256 / hd) : 4;
-    float s = 0.f;
-    if (p < np)
-      for (int o = p; o < OD; o += np) s += params[mp.wo + (long long)o * hd + j] * dout[o];
-    if (p < 4) part[p][j] = s;
-    __syncthreads();
-    if (tid < hd) {
-      float t = 0.f;
-      for (int q = 0; q < np && q < 4; ++q) t += part[q][tid];
-      if (hmask) t *= hmask[r * hd + tid];
-      // leaky backward needs the pre-activation sign: y2 = xh2*g2 + be2
-      float xh2 = sv[E + 2 * hd + tid];
-      float y2 = xh2 * params[mp.g2 + tid] + params[mp.be2 + tid];
-      float dy = t * (y2 > 0.f ? 1.f : 0.01f);
-      rg[OD + hd + tid] = dy;            // dy2
-      da[tid] = dy * params[mp.g2 + tid];  // dxhat2
-    }
-    __syncthreads();
-    if (tid == 0) {
+  // ---- da2m[j] = sum_o Wout[o][j] dout[o] ; LN2 / leaky backward ----
+  matvec_cols<VEC>(params + mp.wo, dout, OD, hd, part, t2);
+  // mean terms of a LayerNorm backward over the first hd threads' da[] (and da * xhat)
+  auto ln_means = [&](const float* xhat) {
+    if (tid < 64) {
       float m1 = 0.f, m2 = 0.f;
-      for (int i = 0; i < hd; ++i) {
+      for (int i = tid; i < hd; i += 64) {
         m1 += da[i];
-        m2 += da[i] * sv[E + 2 * hd + i];
+        m2 += da[i] * xhat[i];
       }
-      st[0] = m1 / hd;
-      st[1] = m2 / hd;
+      m1 = wave_sum(m1);
+      m2 = wave_sum(m2);
+      if (tid == 0) {
+        st[0] = m1 / hd;
+        st[1] = m2 / hd;
+      }
     }
     __syncthreads();
-    if (tid < hd) {
-      float v = sv[E + 4 * hd + 1] * (da[tid] - st[0] - sv[E + 2 * hd + tid] * st[1]);
-      dz[tid] = v;
-      rg[OD + tid] = v;  // dz2
-    }
-    __syncthreads();
-  }
-  // ---- da1[i] = sum_j W3[j][i] dz2[j] ; LN1 / leaky backward ----
+  };
   if (tid < hd) {
-    float s = 0.f;
-    for (int j = 0; j < hd; ++j) s += params[mp.w3 + j * hd + tid] * dz[j];
-    float xh1 = sv[E + tid];
-    float y1 = xh1 * params[mp.g1 + tid] + params[mp.be1 + tid];
-    float dy = s * (y1 > 0.f ? 1.f : 0.01f);
+    float t = t2[tid];
+    if (hmask) t *= hmask[r * hd + tid];
+    // leaky backward needs the pre-activation sign: y2 = xh2*g2 + be2
+    const float xh2 = sv[E + 2 * hd + tid];
+    const float y2 = xh2 * params[mp.g2 + tid] + params[mp.be2 + tid];
+    const float dy = t * (y2 > 0.f ? 1.f : 0.01f);
+    rg[OD + hd + tid] = dy;              // dy2
+    da[tid] = dy * params[mp.g2 + tid];  // dxhat2
+  }
+  __syncthreads();
+  ln_means(sv + E + 2 * hd);
+  if (tid < hd) {
+    const float v = sv[E + 4 * hd + 1] * (da[tid] - st[0] - sv[E + 2 * hd + tid] * st[1]);
+    dz[tid] = v;
+    rg[OD + tid] = v;  // dz2
+  }
+  __syncthreads();
+  // ---- da1[i] = sum_j W3[j][i] dz2[j] ; LN1 / leaky backward ----
+  matvec_cols<VEC>(params + mp.w3, dz, hd, hd, part, t2);
+  if (tid < hd) {
+    const float xh1 = sv[E + tid];
+    const float y1 = xh1 * params[mp.g1 + tid] + params[mp.be1 + tid];
+    const float dy = t2[tid] * (y1 > 0.f ? 1.f : 0.01f);
     rg[OD + 3 * hd + tid] = dy;  // dy1
     da[tid] = dy * params[mp.g1 + tid];
   }
   __syncthreads();
-  if (tid == 0) {
-    float m1 = 0.f, m2 = 0.f;
-    for (int i = 0; i < hd; ++i) {
-      m1 += da[i];
-      m2 += da[i] * sv[E + i];
-    }
-    st[0] = m1 / hd;
-    st[1] = m2 / hd;
-  }
-  __syncthreads();
+  ln_means(sv + E);
   if (tid < hd) {
     const float v = sv[E + 4 * hd] * (da[tid] - st[0] - sv[E + tid] * st[1]);
     rg[OD + 2 * hd + tid] = v;  // dz1
@@ -232,11 +309,8 @@ __global__ __launch_bounds__(256) void mapper_bwd_rows_kernel(MapperParams mp, c
   }
   if (denc) {  // legacy mapper: gradient w.r.t. the first layer's input, d enc[i] = sum_j W0[j][i] dz1[j]
     __syncthreads();
-    if (tid < E) {
-      float s = 0.f;
-      for (int j = 0; j < hd; ++j) s += params[mp.w0 + j * E + tid] * dz[j];
-      denc[(long long)r * E + tid] = s;
-    }
+    matvec_cols<VEC>(params + mp.w0, dz, hd, E, part, t2);
+    if (tid < E) denc[(long long)r * E + tid] = t2[tid];
   }
 }
 
@@ -349,11 +423,22 @@ __global__ __launch_bounds__(256) void mapper_bwd_reduce_kernel(MapperParams mp,
     sa = i;  // enc
     sb = OD + 2 * hd + j;
   }
+  // eight rows' loads in flight per thread (the loop is a chain of L2 round trips otherwise); same summation order
   float s = 0.f;
-  for (int r = 0; r < R; ++r) {
-    float a = sa >= 0 ? save[(long long)r * ssz + sa] : 1.f;
-    s += a * rowgrads[(long long)r * gsz + sb];
+  const float* sp = save + (sa >= 0 ? sa : 0);
+  const float* gp = rowgrads + sb;
+  int r = 0;
+  for (; r + 8 <= R; r += 8) {
+    float a[8], g[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = sp[(long long)(r + u) * ssz];
+      g[u] = gp[(long long)(r + u) * gsz];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (sa >= 0 ? a[u] : 1.f) * g[u];
   }
+  for (; r < R; ++r) s += (sa >= 0 ? sp[(long long)r * ssz] : 1.f) * gp[(long long)r * gsz];
   grads[p] = accumulate ? grads[p] + s : s;
 }
 
@@ -690,6 +775,13 @@ int fill_mp(MapperParams& mp, int E, int hd, int D, int has_bypass) {
   return o;
 }
 
+// 16-byte weight loads need every matrix of the bucket on a 16-byte boundary (for every slot of a multi-mapper bucket)
+// and row lengths that are multiples of 4; MT / (row length / 4) partitions must exist for the transposed products
+bool mapper_vec_ok(const MapperParams& mp, const float* params, long long slot_stride) {
+  return ((uintptr_t)params & 15) == 0 && slot_stride % 4 == 0 && mp.E % 4 == 0 && mp.hd % 4 == 0 && mp.w0 % 4 == 0 &&
+         mp.w3 % 4 == 0 && mp.wo % 4 == 0 && mp.E / 4 <= MT && mp.hd / 4 <= MT;
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -715,8 +807,12 @@ extern "C" int vneti_mapper_fwd(const float* params, const int* slot, long long 
              enc_dim, hidden, D);
   VN_REQUIRE(params && word && save && R > 0 && (enc_in || (data && w_enc && nfeat > 0)) && (!has_bypass || bypass),
              "mapper_fwd: bad arguments");
-  hipLaunchKernelGGL(mapper_fwd_kernel, dim3(R), dim3(256), 0, ST, mp, params, slot, slot_stride, data, nfeat, w_enc, hidden_mask,
-                     norm_scale, word, bypass, save, enc_in);
+  if (mapper_vec_ok(mp, params, slot_stride))
+    hipLaunchKernelGGL(mapper_fwd_kernel<true>, dim3(R), dim3(MT), 0, ST, mp, params, slot, slot_stride, data, nfeat, w_enc,
+                       hidden_mask, norm_scale, word, bypass, save, enc_in);
+  else
+    hipLaunchKernelGGL(mapper_fwd_kernel<false>, dim3(R), dim3(MT), 0, ST, mp, params, slot, slot_stride, data, nfeat, w_enc,
+                       hidden_mask, norm_scale, word, bypass, save, enc_in);
   return vneti_check_launch("mapper_fwd");
 }
 
@@ -731,8 +827,12 @@ extern "C" int vneti_mapper_bwd(const float* params, const int* slot, long long 
   VN_REQUIRE(np > 0, "mapper_bwd: unsupported dims E=%d hd=%d D=%d", enc_dim, hidden, D);
   VN_REQUIRE(params && word && dword_src && dword_rows && save && rowgrads && grads && R > 0,
              "mapper_bwd: bad arguments");
-  hipLaunchKernelGGL(mapper_bwd_rows_kernel, dim3(R), dim3(256), 0, ST, mp, params, slot, slot_stride, hidden_mask, norm_scale, word,
-                     dword_src, dword_rows, ld_src, dbypass, save, rowgrads, denc);
+  if (mapper_vec_ok(mp, params, slot_stride))
+    hipLaunchKernelGGL(mapper_bwd_rows_kernel<true>, dim3(R), dim3(MT), 0, ST, mp, params, slot, slot_stride, hidden_mask,
+                       norm_scale, word, dword_src, dword_rows, ld_src, dbypass, save, rowgrads, denc);
+  else
+    hipLaunchKernelGGL(mapper_bwd_rows_kernel<false>, dim3(R), dim3(MT), 0, ST, mp, params, slot, slot_stride, hidden_mask,
+                       norm_scale, word, dword_src, dword_rows, ld_src, dbypass, save, rowgrads, denc);
   hipLaunchKernelGGL(mapper_bwd_reduce_kernel, dim3(cdiv(np, 256)), dim3(256), 0, ST, mp, R, save,
                      (const float*)rowgrads, grads, np, accumulate, slot, slot_stride);
   return vneti_check_launch("mapper_bwd");
