@@ -41,7 +41,8 @@ TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3
               7: "gemm_kernel<256,128,64,32,ring3>", 8: "gemm_kernel<256,128,64,32>", 9: "gemm_kernel<128,128,64,32>",
               10: "gemm_kernel<128,128,64,32,ring3>", 11: "gemm_kernel<128,64,64,32,ring3>", 12: "gemm_kernel<64,64,32,32,ring3>",
               13: "gemm_kernel<128,128,64,32,ring4>", 14: "gemm_kernel<128,64,64,32,ring4>", 15: "gemm_kernel<64,64,32,32,ring4>",
-              16: "gemm8_kernel<256,256,8-phase>", 17: "gemm8_kernel<256,128,8-phase>"}
+              16: "gemm8_kernel<256,256,8-phase>", 17: "gemm8_kernel<256,128,8-phase>",
+              18: "gemm8_kernel<256,128,8-phase,halo>"}
 # algorithmic FLOPs per sample at 512^2, SD-1.5: VAE 1116.7 + CLIP 16x13.3 + UNet fwd 803.3
 # + UNet dgrad 929.4 + CLIP dgrad 216 GF
 ALGO_GFLOP_PER_SAMPLE_512 = 3278.0

@@ -74,7 +74,11 @@ typedef struct vneti_gemm_desc {
                          10 / 11 / 12: the 3-stage ring on 128x128 (8 waves) / 128x64 / 64x64 (under-filled grids: 2 stages in flight);
                          13 / 14 / 15: the same three tiles with a 4-stage ring (three stages in flight: short-K, latency-bound launches);
                          16 / 17: 256x256 / 256x128 as 8 waves in the 8-phase ping-pong structure (csrc/gemm8.hip; f16 out,
-                         tap-major convs without fused upsampling; other launches fall back to 5 / 7);
+                         convs without fused upsampling; other launches fall back to 5 / 7);
+                         18: the halo-patch form of 17 for stride-1 pad-1 3x3 forward convolutions with chunk-major K
+                         (conv_korder 1) on a 16-pixel grid: a block owns 16 x 16 output pixels and keeps the 18 x 18 input
+                         patch of a 64-channel chunk in LDS for all nine taps (bit-identical to 17; no split-K; other
+                         launches fall back to 17);
                          +100 selects the register-staged (non LDS-DMA) reference variant */
   /* split-K: f32 partials go to `workspace` (>= split_k*batch*M*N*4 bytes) and a second kernel
      reduces them and applies the epilogue.  split_k 0 = heuristic (only if a workspace is given),

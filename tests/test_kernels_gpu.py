@@ -251,7 +251,7 @@ def _nhwc(x):
 
 @pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
 @pytest.mark.parametrize("case", ["s1", "s2p1", "s2vae", "ups"])
-@pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 13, 15, 16, 17, 101, 103])
+@pytest.mark.parametrize("hint", [0, 1, 3, 4, 5, 6, 7, 8, 9, 13, 15, 16, 17, 18, 101, 103])
 def test_conv3x3_fwd(case, hint, korder):
     """both K orders of the implicit GEMM (vneti_gemm_desc.conv_korder): (tap, channel) and (64-channel chunk, tap,
     channel); two chunks so that the orders really differ"""
@@ -281,6 +281,53 @@ def test_conv3x3_fwd(case, hint, korder):
              M=Bn * Ho * Wo, tile_hint=hint)
     torch.cuda.synchronize()
     check(f"conv {case} hint{hint} korder{korder}", out.view(Bn, Ho, Wo, Co), _nhwc(ref), 2e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128, 32, 48), (1, 192, 320, 16, 32), (2, 256, 96, 32, 16), (3, 64, 128, 16, 16)],
+                         ids=["2chunks", "3chunks-Ntail", "4chunks-N96", "1chunk"])
+@pytest.mark.parametrize("epi", ["bias", "resid+rowadd+gn", "silu"])
+def test_conv3x3_halo_tile(shape, epi):
+    """tile_hint 18 (16 x 16-pixel blocks, the 18 x 18 input patch resident in LDS for all nine taps) against F.conv2d and,
+    bit for bit, against the row-major 8-phase tile 17 — with the fused epilogue operands of the UNet's resnet convs (time
+    embedding row-add, residual, GroupNorm sums of the output) addressed through the tile's pixel order"""
+    ops = _ops()
+    from view_neti_amd import packing
+    Bn, Ci, Co, H, W = shape
+    x = rnd(Bn, Ci, H, W, seed=21)
+    w = rnd(Co, Ci, 3, 3, scale=1 / math.sqrt(9 * Ci), seed=22)
+    bias = rnd(Co, seed=23, dtype=torch.float32)
+    M = Bn * H * W
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    kw = dict(bias=bias.to(DEV))
+    G = Co // 8  # (the fused statistics need at least 8 channels per group)
+    if epi == "resid+rowadd+gn":
+        res = rnd(M, Co, seed=24)
+        temb = rnd(Bn, Co, seed=25)
+        ref = ref + res.float().view(Bn, H, W, Co).permute(0, 3, 1, 2) + temb.float()[:, :, None, None]
+        kw.update(resid=res.to(DEV), rowadd=temb.to(DEV), rows_per_group=H * W)
+    elif epi == "silu":
+        ref = F.silu(ref)
+        kw.update(act=1)
+    conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci, korder=1)
+    outs, sums = {}, {}
+    for hint in (17, 18):
+        out = torch.zeros(M, Co, dtype=torch.float16, device=DEV)
+        k2 = dict(kw)
+        if epi == "resid+rowadd+gn":
+            sums[hint] = torch.zeros(Bn, 4, G, 4, dtype=torch.int64, device=DEV)
+            k2.update(gn_sums=sums[hint], gn_hw=H * W, gn_groups=G, gn_slots=4)
+        ops.gemm(_nhwc(x).to(DEV), packing.conv3x3_fwd(w, cm=True).to(DEV), out, conv=conv, M=M, tile_hint=hint, split_k=1, **k2)
+        torch.cuda.synchronize()
+        outs[hint] = out
+    check(f"conv halo {shape} {epi}", outs[18].view(Bn, H, W, Co), _nhwc(ref), 4e-3)
+    assert torch.equal(outs[17], outs[18]), "tile 18 differs from tile 17"
+    if sums:
+        # (the f32 per-thread partials group the pixels differently in the two orders: equal to f32 rounding, not bit for bit)
+        got, got17 = ops.gn_sums_decode(sums[18].sum(1)), ops.gn_sums_decode(sums[17].sum(1))
+        assert (got - got17).abs().max() <= 1e-6 * got17.abs().max(), "GroupNorm sums differ between the pixel orders"
+        xg = outs[18].double().cpu().view(Bn, H * W, G, Co // G)
+        check("halo gn sum", got[..., 0].float(), xg.sum((1, 3)).float(), 1e-4)
+        check("halo gn sumsq", got[..., 1].float(), (xg * xg).sum((1, 3)).float(), 1e-4)
 
 
 @pytest.mark.parametrize("hint", [3, 16, 17])

@@ -61,3 +61,12 @@ for (Bn, H, W, Ci, Co) in [(4, 256, 256, 256, 256), (4, 128, 128, 512, 512), (4,
     conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci)
     report(f"conv {H}x{W} {Ci}->{Co}", lambda: ops.gemm(x, w, y, M=Bn * H * W, conv=conv, tile_hint=16, workspace=ws, split_k=1),
            (Bn * H * W // 256) * ((Co + 255) // 256))
+# the N = 128 convolution of the VAE: row-major 256x128 tile (17) against its halo-patch form (18, chunk-major K)
+for hint in (17, 18):
+    Bn, H, W, Ci, Co = 4, 512, 512, 128, 128
+    x = torch.randn(Bn * H * W, Ci, device=dev).half()
+    w = (torch.randn(Co, 9 * Ci, device=dev) * 0.03).half()
+    y = torch.empty(Bn * H * W, Co, device=dev, dtype=torch.float16)
+    conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci, korder=1 if hint == 18 else 0)
+    report(f"conv {H}x{W} {Ci}->{Co} tile {hint}", lambda: ops.gemm(x, w, y, M=Bn * H * W, conv=conv, tile_hint=hint, workspace=ws, split_k=1),
+           Bn * H * W // 256)

@@ -48,7 +48,17 @@ constexpr int GN_IMG = 5;
 #define VN_STAMP(i)
 #endif
 
+// tools/lab/gemm8_parts.py builds variants with pieces of the main loop removed (results are garbage) to see what the loop
+// waits for: bit 0 no MFMAs, 1 no fragment reads, 2 no staging DMAs, 3 the A gather folded into a 256 KiB window (always
+// L2 hits).  0 in the product build.
+#ifndef VN_GEMM8_LAB
+#define VN_GEMM8_LAB 0
+#endif
+#if VN_GEMM8_LAB & 16  // (lab: no waits for the stagings inside the loops — a data race, only the duration means anything)
+#define VN_WAIT_VM(n) asm volatile("" ::: "memory")
+#else
 #define VN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
 #define VN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // BN = 256: the structure of the header.  BN = 128 (the N = 128 convolutions of the VAE at 512^2 / 256^2 and the N = 320 / 640
@@ -58,9 +68,21 @@ constexpr int GN_IMG = 5;
 //     Q1: read A1(t)             [8]                  stage A1 of tile t+2       (2 LDS-DMAs)   C10 += A1.B0, C11 += A1.B1   vmcnt(8)
 // (stream position 12 + 6t .. is issued in tile t; a half tile is read four phases after its staging and restaged two
 // phases after its last read.)
-template <int BN, int EPI, bool CONV>
+//
+// HALO (BN = 128, stride-1 3x3 forward convolutions with chunk-major K): the implicit GEMM fetches every input pixel nine
+// times, and tools/lab/gemm8_parts.py shows the N = 128 convolutions of the VAE waiting for exactly that — staging alone
+// (no MFMAs, no fragment reads) takes 60 % of the launch, whether or not the gather hits L2: 48 KiB per K-tile through a
+// fill path that moves (bytes in flight) / (latency).  Here a block owns a 16 x 16 pixel tile instead of 256 consecutive
+// pixels; the 18 x 18 x 64-channel input patch of a channel chunk is DMA'd into LDS ONCE (41 KiB, two chunk slots, the
+// next chunk's patch trickles in one DMA per K-tile) and the A fragments of all nine taps are read straight out of it
+// (pixel (y + dy, x + dx): a different LDS address, not a different copy).  Only the 16 KiB B tile is staged per K-tile
+// (ring of three): 2.3x fewer bytes through the fill path.  Logical block row r <-> pixel (r / 16, r % 16) of the tile;
+// the epilogue writes row r to that pixel, so results are bit-identical to the row-major tiles.
+template <int BN, int EPI, bool CONV, bool HALO = false>
 __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   static_assert(BN == 256 || BN == 128, "tile width");
+  static_assert(!HALO || (BN == 128 && CONV), "the halo-patch loop exists for the 256x128 convolution tile");
+  constexpr int PATCH_STRIDE = 48 * 1024;  // 324 pixels x 128 B = 40.5 KiB, padded to the 48 wave-DMAs that fill it
   constexpr int NJB = BN / 128;                 // 16-column blocks a wave owns in each B half
   constexpr int HB_BYTES = (BN / 2) * 128;      // a B half tile
   constexpr int HB_DMA = BN / 128;              // LDS-DMAs per thread and B half tile (64 rows each)
@@ -68,7 +90,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   constexpr int BUF_BYTES = 2 * HALF_BYTES + 2 * HB_BYTES;  // A0 A1 B0 B1 of one K-tile
   constexpr int CS_LD = BN + 8;
   constexpr int CS_BYTES = BM * CS_LD * 2;
-  constexpr int LDS_BYTES = CS_BYTES > NBUF * BUF_BYTES ? CS_BYTES : NBUF * BUF_BYTES;
+  constexpr int LOOP_BYTES = HALO ? 2 * PATCH_STRIDE + 3 * 2 * HB_BYTES : NBUF * BUF_BYTES;
+  constexpr int LDS_BYTES = CS_BYTES > LOOP_BYTES ? CS_BYTES : LOOP_BYTES;
   constexpr int GN_NG = BN / 4 + 2;
   const half_t* const e_gate = EPI == 2 ? g.gate_src : nullptr;
   half_t* const e_C2 = EPI == 2 ? g.C2 : nullptr;
@@ -99,6 +122,17 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   const int n0 = tile_n * BN;
   const int bz = blockIdx.y;
   const int kz = blockIdx.z;
+  // HALO: tile_m counts 16 x 16 pixel tiles in (image, tile row, tile column) order; row0 = the tile's first output row
+  int hb = 0, hty = 0, htx = 0, row0 = m0;
+  if constexpr (HALO) {
+    const int tpr = g.Wo >> 4, tpi = (g.Ho >> 4) * tpr;
+    hb = tile_m / tpi;
+    const int rem = tile_m - hb * tpi;
+    hty = rem / tpr;
+    htx = rem - hty * tpr;
+    row0 = (hb * g.Ho + hty * 16) * g.Wo + htx * 16;
+  }
+  auto rowmem = [&](const int r) { return HALO ? row0 + (r >> 4) * g.Wo + (r & 15) : m0 + r; };
 
   const half_t* Ab = g.A + (long long)bz * g.strideA;
   const half_t* Bb = g.B + (long long)bz * g.strideB;
@@ -125,7 +159,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   int a_base[4];
   uint32_t a_mask[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < (HALO ? 0 : 4); ++r) {
     const int m = m0 + (r >> 1) * 128 + (r & 1) * 64 + lrow;
     const bool ok = m < g.M;
     if constexpr (!CONV) {
@@ -216,7 +250,10 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) nxt[j] = (a_mask[2 * h + j] & tapbit) ? (uint32_t)(a_base[2 * h + j] + soff) : VN_OOB;
+    for (int j = 0; j < 2; ++j) {
+      nxt[j] = (a_mask[2 * h + j] & tapbit) ? (uint32_t)(a_base[2 * h + j] + soff) : VN_OOB;
+      if constexpr (VN_GEMM8_LAB & 8) nxt[j] &= 0x3FFFFu;
+    }
     a_kt[h] += 1;
   };
   auto prepB = [&](const int h) {  // BN = 256: into nxt[0..1]; BN = 128: into nxt[2 + h]
@@ -233,11 +270,13 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   auto issueA = [&](const int h, const int buf) {
     char* dst = smem + buf * BUF_BYTES + h * HALF_BYTES + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(rsA, dst + j * 8192, nxt[j]);
+    for (int j = 0; j < 2; ++j)
+      if (!(VN_GEMM8_LAB & 4)) dma16(rsA, dst + j * 8192, nxt[j]);
   };
   auto issueB = [&](const int h, const int buf) {
     char* dst = smem + buf * BUF_BYTES + 2 * HALF_BYTES + h * HB_BYTES + wave * 1024;
-    if constexpr (BN == 256) {
+    if constexpr (VN_GEMM8_LAB & 4) {
+    } else if constexpr (BN == 256) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) dma16(rsB, dst + j * 8192, nxt[j]);
     } else {
@@ -258,38 +297,58 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     rdB[s] = 2 * HALF_BYTES + (wc * (16 * NJB) + frow) * 128 + ch;
   }
   half8 af[4][2], bf0[NJB][2], bf1[NJB][2];
+  if constexpr (VN_GEMM8_LAB & 2) {  // (lab build without fragment reads: defined, non-constant operands)
+    const half_t v = (half_t)(float)(lane & 3);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i][s] = half8{v, v, v, v, v, v, v, v};
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) bf0[jb][s] = bf1[jb][s] = half8{v, v, v, v, v, v, v, v};
+    }
+  }
   auto readA = [&](const int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        af[i][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdA[s] + h * HALF_BYTES + i * 2048));
+        if (!(VN_GEMM8_LAB & 2)) af[i][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdA[s] + h * HALF_BYTES + i * 2048));
   };
   auto readB0 = [&](const int flip) {  // flip = BUF_BYTES: from the other K-tile buffer (BN = 256)
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) bf0[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + (rdB[s] ^ flip) + jb * 2048));
+      for (int s = 0; s < 2; ++s)
+        if (!(VN_GEMM8_LAB & 2)) bf0[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + (rdB[s] ^ flip) + jb * 2048));
   };
   auto readB1 = [&]() {
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        bf1[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdB[s] + HB_BYTES + jb * 2048));
+        if (!(VN_GEMM8_LAB & 2)) bf1[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdB[s] + HB_BYTES + jb * 2048));
   };
 
   // the bias of this lane's 16 columns, requested before the main loop (its L2 round trip would otherwise sit between
   // the last MFMA and the first C-tile write); out-of-range columns and a null bias read as zeros
-  f32x4 bv[2][NJB];
+  // HALO: the waves form a 4 x 2 grid of 64 x 64 tiles (wave tile 128 x 32 re-reads A from LDS four times per block and
+  // makes the 256 x 128 tile LDS-read-bound: 160 KiB per K-tile against ~183 B/clk; 64 x 64 needs 128 KiB) — accumulator
+  // [h][j][i][0] is then row block i of the wave's 64 rows, column block 2h + j of its 64 columns.
+  const int wr4 = wave >> 1, wc2 = wave & 1;
+  auto acc_row = [&](const int h, const int i) { return HALO ? wr4 * 64 + i * 16 + frow : h * 128 + wr * 64 + i * 16 + frow; };
+  auto acc_col = [&](const int h, const int j, const int jb) {
+    return HALO ? wc2 * 64 + (2 * h + j) * 16 + 4 * fq : j * (BN / 2) + wc * (16 * NJB) + jb * 16 + 4 * fq;
+  };
+  f32x4 bv[HALO ? 2 : 1][2][NJB];
   {
     const __amdgpu_buffer_rsrc_t rsBias = vn_make_rsrc(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int h = 0; h < (HALO ? 2 : 1); ++h)
 #pragma unroll
-      for (int jb = 0; jb < NJB; ++jb)
-        bv[j][jb] = __builtin_bit_cast(
-            f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + j * (BN / 2) + wc * (16 * NJB) + jb * 16 + 4 * fq) * 4u));
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb)
+          bv[h][j][jb] = __builtin_bit_cast(f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + acc_col(h, j, jb)) * 4u));
   }
   f32x4 acc[2][2][4][NJB];
 #pragma unroll
@@ -309,7 +368,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     __builtin_amdgcn_s_setprio(1);                                                                             \
     PREP;                                                                                                      \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                \
-        _Pragma("unroll") for (int jb = 0; jb < NJB; ++jb) acc[H][J][i][jb] =                                  \
+        _Pragma("unroll") for (int jb = 0; jb < NJB; ++jb) if (VN_GEMM8_LAB & 1)                               \
+            asm volatile("" : "+v"(acc[H][J][i][jb]) : "v"(BF[jb][s]), "v"(af[i][s])); else acc[H][J][i][jb] = \
             __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[jb][s], af[i][s], acc[H][J][i][jb], 0, 0, 0);           \
     __builtin_amdgcn_s_setprio(0);                                                                             \
   } while (0)
@@ -325,7 +385,150 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);     \
   } while (0)
 
-  if constexpr (BN == 256) {
+  // two quadrants that share the A fragments: 16 MFMAs (one 16-column block per B half)
+#define VN_MMA2(H, PREP)                                                                                       \
+  do {                                                                                                         \
+    VN_WAIT_LGKM0();                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    PREP;                                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i) {              \
+      if (VN_GEMM8_LAB & 1) {                                                                                  \
+        asm volatile("" : "+v"(acc[H][0][i][0]), "+v"(acc[H][1][i][0]) : "v"(bf0[0][s]), "v"(bf1[0][s]), "v"(af[i][s])); \
+      } else {                                                                                                 \
+      acc[H][0][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[0][s], af[i][s], acc[H][0][i][0], 0, 0, 0); \
+      acc[H][1][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[0][s], af[i][s], acc[H][1][i][0], 0, 0, 0); \
+      }                                                                                                        \
+    }                                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+  } while (0)
+#define VN_SYNC(n)                         \
+  do {                                     \
+    VN_WAIT_VM(n);                         \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+  if constexpr (HALO) {
+    constexpr int BRING = 2 * PATCH_STRIDE, BBUF = 2 * HB_BYTES;  // the B ring: three K-tiles of 16 KiB behind the two patch slots
+    constexpr int PROW = 18 * 128;                                // bytes per patch row (18 pixels x 64 channels)
+    const int nchunk = g.Ci >> 6;
+    // ---- patch staging: wave-DMA (j, wave) covers 64 consecutive 16-byte slots q = (8j + wave) * 64 + lane of a slot; slot
+    // q = pixel p = q / 8 (row-major in the 18 x 18 patch), physical chunk q % 8, which holds the logical chunk
+    // (q % 8) ^ ((px >> 1) & 7) — a 16-lane fragment read walks 16 consecutive px of one patch row, so keying the swizzle by
+    // px keeps it conflict free for every tap.  Pixels outside the image (the zero padding) and the 384 - 324 pad slots
+    // fetch nothing (out-of-range offset => zeros).
+    uint32_t pa_off[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int q = (j * 8 + wave) * 64 + lane, p = q >> 3, cs = q & 7;
+      const int py = (p * 3641) >> 16;  // p / 18 for p < 3000
+      const int px = p - py * 18;
+      const int iy = hty * 16 + py - 1, ix = htx * 16 + px - 1;
+      const bool ok = p < 324 && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+      pa_off[j] = ok ? (uint32_t)(((hb * g.Hi + iy) * g.Wi + ix) * g.ldx2 + ((cs ^ ((px >> 1) & 7)) << 4)) : VN_OOB;
+    }
+    auto issueP = [&](const int j, const int chunk) {  // + chunk * 128 keeps an out-of-range offset out of range (< 2 GiB)
+      if (!(VN_GEMM8_LAB & 4))
+        dma16(rsA, smem + (chunk & 1) * PATCH_STRIDE + (j * 8 + wave) * 1024, pa_off[j] + (uint32_t)chunk * 128u);
+    };
+    auto issueBt = [&](const int kt, const int buf) {  // both 64-column halves of K-tile kt
+      const uint32_t soff = (uint32_t)kt * 128u, dead = kt < T ? 0u : VN_OOB;
+      char* dst = smem + BRING + buf * BBUF + wave * 1024;
+      if (!(VN_GEMM8_LAB & 4)) {
+        dma16(rsB, dst, (b_base[0] + soff) | dead);
+        dma16(rsB, dst + HB_BYTES, (b_base[2] + soff) | dead);
+      }
+    };
+    // fragment reads: lane (frow = pixel column of the tile row, fq = 8-channel chunk of the k32 sub-step)
+    int lb[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) lb[dx] = (wr4 * 4) * PROW + (frow + dx) * 128 + ((fq ^ (((frow + dx) >> 1) & 7)) << 4);
+    const int rb0 = (wc2 * 64 + frow) * 128 + ((fq ^ fkey) << 4);  // (sub-step 1: ^ 64 = chunk + 4)
+    half8 bfh[4][2];  // the wave's four 16-column blocks of a B tile: read in Q0, held over both phases
+    if constexpr (VN_GEMM8_LAB & 2) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) bfh[cb][0] = bfh[cb][1] = af[0][0];
+    }
+    auto readAh = [&](const int half, const int ab) {  // tile rows 2 * half, 2 * half + 1 of the wave's four, at tap offset ab
+#pragma unroll
+      for (int i = 2 * half; i < 2 * half + 2; ++i) {
+        if (VN_GEMM8_LAB & 2) continue;
+        af[i][0] = as_half8(*reinterpret_cast<const u32x4*>(smem + ab + i * PROW));
+        af[i][1] = as_half8(*reinterpret_cast<const u32x4*>(smem + (ab ^ 64) + i * PROW));
+      }
+    };
+    auto readBh = [&](const int buf) {
+      const char* b = smem + BRING + buf * BBUF;
+      if (VN_GEMM8_LAB & 2) return;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        bfh[cb][0] = as_half8(*reinterpret_cast<const u32x4*>(b + cb * 2048 + rb0));
+        bfh[cb][1] = as_half8(*reinterpret_cast<const u32x4*>(b + cb * 2048 + (rb0 ^ 64)));
+      }
+    };
+    // 16 MFMAs: two row blocks x four column blocks x two k32 sub-steps (accumulator [h][j][i] = column block 2h + j)
+#define VN_MMA4(HALF)                                                                                          \
+  do {                                                                                                         \
+    VN_WAIT_LGKM0();                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 2 * HALF; i < 2 * HALF + 2; ++i) \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                     \
+      if (VN_GEMM8_LAB & 1) {                                                                                  \
+        asm volatile("" : "+v"(acc[cb >> 1][cb & 1][i][0]) : "v"(bfh[cb][s]), "v"(af[i][s]));                  \
+      } else {                                                                                                 \
+        acc[cb >> 1][cb & 1][i][0] =                                                                           \
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0); \
+      }                                                                                                        \
+    }                                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+  } while (0)
+    // ---- prologue: the whole patch of chunk 0, B tiles 0 and 1 ----
+#pragma unroll
+    for (int j = 0; j < 6; ++j) issueP(j, 0);
+    issueBt(0, 0);
+    issueBt(1, 1);
+    VN_WAIT_VM(2);  // patch 0 and B tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    VN_STAMP(1);
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
+    // K-tile t = (chunk c, tap): Q0 reads the wave's four column blocks of B(t) and two of its four tile rows at the tap's
+    // offset [12 ds_read_b128], stages B(t + 2) [its buffer was last read in Q0(t - 1)] [+ one DMA of chunk c + 1's patch at
+    // taps 1..6: its slot was last read in Q1 of the previous chunk's tap 8, three phases before]; Q1 reads the other two
+    // tile rows [4] and waits for B(t + 1) (read in the next Q0): everything but this tile's stagings, which come later in
+    // the stream.
+    int c = 0, tap = 0, rbuf = 0, sbuf = 2;
+    for (int t = 0; t < T; ++t) {
+      const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+      const int ab = (dx == 0 ? lb[0] : (dx == 1 ? lb[1] : lb[2])) + (c & 1) * PATCH_STRIDE + dy * PROW;
+      const bool stage_p = tap >= 1 && tap <= 6 && c + 1 < nchunk;
+      // Q0
+      readBh(rbuf);
+      readAh(0, ab);
+      if (stage_p) issueP(tap - 1, c + 1);
+      issueBt(t + 2, sbuf);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      VN_MMA4(0);
+      VN_PHASE_END();
+      // Q1
+      readAh(1, ab);
+      if (stage_p) {
+        VN_SYNC(3);
+      } else {
+        VN_SYNC(2);
+      }
+      VN_MMA4(1);
+      VN_PHASE_END();
+      tap += 1;
+      if (tap == 9) {
+        tap = 0;
+        c += 1;
+      }
+      rbuf = rbuf == 2 ? 0 : rbuf + 1;
+      sbuf = sbuf == 2 ? 0 : sbuf + 1;
+    }
+  } else if constexpr (BN == 256) {
     // ---- prologue: tile 0 and three half tiles of tile 1 (stream positions 0..6) ----
     prepB(0);
     issueB(0, 0);
@@ -386,24 +589,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       }
     }
   } else {
-    // two quadrants that share the A fragments: 16 MFMAs (one 16-column block per B half)
-#define VN_MMA2(H, PREP)                                                                                       \
-  do {                                                                                                         \
-    VN_WAIT_LGKM0();                                                                                           \
-    __builtin_amdgcn_s_setprio(1);                                                                             \
-    PREP;                                                                                                      \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i) {              \
-      acc[H][0][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[0][s], af[i][s], acc[H][0][i][0], 0, 0, 0); \
-      acc[H][1][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[0][s], af[i][s], acc[H][1][i][0], 0, 0, 0); \
-    }                                                                                                          \
-    __builtin_amdgcn_s_setprio(0);                                                                             \
-  } while (0)
-#define VN_SYNC(n)                         \
-  do {                                     \
-    VN_WAIT_VM(n);                         \
-    __builtin_amdgcn_s_barrier();          \
-    __builtin_amdgcn_sched_barrier(0);     \
-  } while (0)
     // ---- prologue: tiles 0 and 1 (stream positions 0..11: [A0 A0 B0 B1 | A1 A1] per tile) ----
 #pragma unroll
     for (int t0 = 0; t0 < 2; ++t0) {
@@ -452,6 +637,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     }
 #undef VN_MMA2
 #undef VN_SYNC
+#undef VN_MMA4
   }
   VN_STAMP(2);
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
@@ -463,7 +649,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 
   // acc[h][j][i][jb][e]  <->  block row h*128 + wr*64 + i*16 + frow, block column j*(BN/2) + wc*16*NJB + jb*16 + 4*fq + e
   // ---- split-K: raw f32 partials straight to the workspace ----
-  if (g.ksplit > 1) {
+  if (!HALO && g.ksplit > 1) {
     float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -505,11 +691,12 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int jb = 0; jb < NJB; ++jb) {
-            const int ml = h * 128 + wr * 64 + i * 16 + frow;
-            const int nl = (j * (BN / 2) + wc * (16 * NJB) + jb * 16 + 4 * fq) ^ nsw;
+            const int ml = acc_row(h, i);
+            const int nl = acc_col(h, j, jb) ^ nsw;
             half4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (half_t)apply_act(acc[h][j][i][jb][e] * g.alpha + bv[j][jb][e], e_act);
+            for (int e = 0; e < 4; ++e)
+              o[e] = (half_t)apply_act(acc[h][j][i][jb][e] * g.alpha + bv[HALO ? h : 0][j][jb][e], e_act);
             *reinterpret_cast<half4*>(smem + ((size_t)ml * CS_LD + nl) * 2) = o;
           }
   }
@@ -529,7 +716,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   vn_u64* gacc = reinterpret_cast<vn_u64*>(smem + LDS_BYTES);
   const bool gn = e_gn_sums != nullptr;
   const float rcp_gnhw = gn ? 1.0f / (float)g.gn_hw : 0.f, rcp_rpg = e_rowadd ? 1.0f / (float)g.rows_per_group : 0.f;
-  const int gn_img0 = gn ? m0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
+  const int gn_img0 = gn ? row0 / g.gn_hw : 0, gn_g0t = gn ? n0 / g.gn_cpg : 0;
   const int c = (tid % CPR) * 8;
   const int n = n0 + c;
   const int gn_glo = gn ? n / g.gn_cpg : 0;
@@ -570,7 +757,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int r = r_first + RPP * (it0 + u);
-      const int m = m0 + r;
+      const int m = rowmem(r);
       const bool ok = m < g.M && full_chunk;
       u32x4 t = *reinterpret_cast<const u32x4*>(smem + ((size_t)r * CS_LD + c) * 2);
       if (swap_halves) t = u32x4{t[2], t[3], t[0], t[1]};
@@ -594,7 +781,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int r = r_first + RPP * (it0 + u);
-      const int m = m0 + r;
+      const int m = rowmem(r);
       const bool valid = m < g.M && n < g.N;
       if (gn) {
         int img = gn_img;
@@ -719,11 +906,17 @@ inline int epilogue_level8(const GemmArgs& g) {
 }  // namespace
 
 // f16 output only; the caller (vneti_gemm_f16) has validated the descriptor, set ksplit / kt_per_split and launches the
-// split-K reduce itself.  Returns VNETI_EUNSUP for what this tile does not carry (f32 output, chunk-major conv K order).
-int vneti_launch_gemm8(void* gemm_args, int bn, hipStream_t st) {
+// split-K reduce itself.  Returns VNETI_EUNSUP for what the requested tile does not carry (f32 output, fused upsample,
+// stride-2 transposed gather; halo: anything but a stride-1 pad-1 3x3 forward convolution on a 16-pixel grid with
+// chunk-major K and no split).
+int vneti_launch_gemm8(void* gemm_args, int bn, int halo, hipStream_t st) {
   GemmArgs& g = *reinterpret_cast<GemmArgs*>(gemm_args);
   if (g.out_f32 || (g.conv_mode && (g.ups || (g.conv_mode == 2 && g.stride == 2))) ||
       (g.M >= (1 << 24) && (g.conv_mode || g.rowadd || g.gn_sums)))  // float-reciprocal row arithmetic: rows < 2^24
+    return VNETI_EUNSUP;
+  if (halo && (bn != 128 || g.conv_mode != 1 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.Hi != g.Ho ||
+               g.Wi != g.Wo || (g.Ho & 15) || (g.Wo & 15) || (g.Ci & 63) || g.K != 9 * g.Ci || !g.korder || g.ksplit != 1 ||
+               g.batch != 1 || g.M != (g.M / (g.Ho * g.Wo)) * g.Ho * g.Wo))
     return VNETI_EUNSUP;
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, bn);
@@ -734,11 +927,15 @@ int vneti_launch_gemm8(void* gemm_args, int bn, hipStream_t st) {
     if (bn == 256) hipLaunchKernelGGL((gemm8_kernel<256, E, C>), grid, block, 0, st, g);   \
     else hipLaunchKernelGGL((gemm8_kernel<128, E, C>), grid, block, 0, st, g);             \
   } while (0)
-  if (g.conv_mode) {
+#define VN_GO_HALO(E) hipLaunchKernelGGL((gemm8_kernel<128, E, true, true>), grid, block, 0, st, g)
+  if (halo) {
+    if (epi == 2) VN_GO_HALO(2); else if (epi == 1) VN_GO_HALO(1); else VN_GO_HALO(0);
+  } else if (g.conv_mode) {
     if (epi == 2) VN_GO(2, true); else if (epi == 1) VN_GO(1, true); else VN_GO(0, true);
   } else {
     if (epi == 2) VN_GO(2, false); else if (epi == 1) VN_GO(1, false); else VN_GO(0, false);
   }
 #undef VN_GO
+#undef VN_GO_HALO
   return vneti_check_launch("gemm8_kernel");
 }

@@ -76,5 +76,6 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 
 }  // namespace
 
-// the 8-phase ping-pong tiles (gemm8.hip): 256 x bn, bn = 256 or 128; g.ksplit / g.kt_per_split already set, f16 output only
-int vneti_launch_gemm8(void* gemm_args, int bn, hipStream_t st);
+// the 8-phase ping-pong tiles (gemm8.hip): 256 x bn, bn = 256 or 128 (halo: the 16 x 16-pixel halo-patch convolution form
+// of the 256 x 128 tile); g.ksplit / g.kt_per_split already set, f16 output only
+int vneti_launch_gemm8(void* gemm_args, int bn, int halo, hipStream_t st);

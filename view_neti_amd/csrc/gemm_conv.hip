@@ -745,10 +745,10 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
 struct TileDims {
   int bm, bn;
 };
-constexpr int kMaxTile = 17;
+constexpr int kMaxTile = 18;
 constexpr TileDims kTiles[kMaxTile + 1] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128}, {256, 256}, {256, 128}, {256, 128},
                                           {256, 128}, {128, 128}, {128, 128}, {128, 64},  {64, 64},   {128, 128}, {128, 64},  {64, 64},
-                                          {256, 256}, {256, 128}};
+                                          {256, 256}, {256, 128}, {256, 128}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -909,6 +909,12 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   VN_REQUIRE(cfg >= 1 && cfg <= kMaxTile, "gemm: unknown tile_hint %d", d->tile_hint);
   // the 8-phase tile: LDS-DMA only; convolutions whose gather offset is linear in the tap (no fused upsample, no
   // stride-2 transposed gather), tap-major K order
+  // the halo-patch form of the 256x128 tile: stride-1 pad-1 3x3 forward convolutions on a 16-pixel grid, chunk-major K,
+  // no split-K; anything else runs as the plain 256x128 8-phase tile
+  if (cfg == 18 && (d->conv_mode != 1 || d->stride != 1 || d->ups || d->pad_t != 1 || d->pad_l != 1 || d->Hi != d->Ho ||
+                    d->Wi != d->Wo || (d->Ho & 15) || (d->Wo & 15) || (d->Ci & 63) || !d->conv_korder || batch != 1 || f32 ||
+                    (d->split_k != 1 && d->split_k != 0)))
+    cfg = 17;
   if ((cfg == 16 || cfg == 17) && (!dma || (d->conv_mode && (d->ups || (d->conv_mode == 2 && d->stride == 2))) ||
                     (d->M >= (1 << 24) && (d->conv_mode || d->rowadd || d->gn_sums)))) cfg = cfg == 16 ? 5 : 7;
   if ((cfg == 5 || cfg == 16) && f32) cfg = 4;
@@ -927,6 +933,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     VN_REQUIRE(batch == 1 || (d->strideC != 0), "gemm: batched split-K needs strideC");
     VN_REQUIRE((long long)batch * d->M * ((d->N + 3) / 4) < 0x7fffffffLL, "gemm: split-K output larger than 2^31 chunks");
   }
+  if (cfg == 18 && ks > 1) cfg = 17;  // (the heuristic chose to split: the halo form does not)
   g.ksplit = ks;
   g.kt_per_split = cdiv(nk, ks);
   g.ksplit = cdiv(nk, g.kt_per_split);  // drop empty trailing splits
@@ -953,8 +960,9 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     case 14: return launch_cfg_ring<128, 64, 64, 32, 4>(g, f32, st);
     case 15: return launch_cfg_ring<64, 64, 32, 32, 4>(g, f32, st);
     case 16:    // 256x256 as 8 waves in the 8-phase ping-pong structure (gemm8.hip)
-    case 17: {  // 256x128, same waves, three K-tile buffers
-      const int rc = vneti_launch_gemm8(&g, cfg == 16 ? 256 : 128, st);
+    case 17:    // 256x128, same waves, three K-tile buffers
+    case 18: {  // 256x128 over a 16 x 16-pixel tile with the input patch resident in LDS (3x3 convolutions)
+      const int rc = vneti_launch_gemm8(&g, cfg == 16 ? 256 : 128, cfg == 18 ? 1 : 0, st);
       if (rc != VNETI_OK) return rc;
       launch_reduce(g, st);
       return vneti_check_launch("gemm8_kernel");

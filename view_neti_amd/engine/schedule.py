@@ -128,7 +128,7 @@ class Schedule:
     _tile_cache: Dict[tuple, int] = {}
     _TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128), 5: (256, 256), 6: (256, 128), 7: (256, 128),
                   8: (256, 128), 9: (128, 128), 10: (128, 128), 11: (128, 64), 12: (64, 64), 13: (128, 128), 14: (128, 64),
-                  15: (64, 64), 16: (256, 256), 17: (256, 128)}
+                  15: (64, 64), 16: (256, 256), 17: (256, 128), 18: (256, 128)}
 
     @staticmethod
     def _gemm_key(f):
@@ -141,7 +141,7 @@ class Schedule:
         ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
         return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32, kw.get("geglu") or 0)
 
-    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17), reps=8):
+    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18), reps=8):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
         tile configuration, with the split-K heuristic and with split-K forced off (the f32 partials
         and the reduce launch are not always worth the extra blocks), and pin the fastest pair.  Launches are
@@ -180,7 +180,12 @@ class Schedule:
                 if key not in cache:
                     best, best_t = (0, 0, 0), float("inf")
                     M_, N_, K_ = key[:3]
-                    variants = [(h, 0) for h in candidates] + ([(h, 1) for h in candidates if h in (16, 17)] if try_cm else [])
+                    # tile 18 = the halo-patch form of 17 (a block owns 16 x 16 pixels, the input patch stays in LDS for all
+                    # nine taps): stride-1 pad-1 3x3 forward convolutions on a 16-pixel grid, chunk-major K only, no split-K
+                    halo_ok = try_cm and conv["mode"] == 1 and conv["stride"] == 1 and conv["pad_t"] == 1 and conv["pad_l"] == 1 \
+                        and conv["Ho"] % 16 == 0 and conv["Wo"] % 16 == 0 and conv["Hi"] == conv["Ho"] and conv["Wi"] == conv["Wo"]
+                    variants = [(h, 0) for h in candidates if h != 18] + \
+                        ([(h, 1) for h in candidates if h in (16, 17) or (h == 18 and halo_ok)] if try_cm else [])
                     if try_cm:
                         B_cm = packing._chunk_major(f.args[1], f.args[1].shape[0], conv["Ci"])
                     for h, ko in variants:
@@ -190,8 +195,8 @@ class Schedule:
                         sks = (0, 1) + (tuple(x for x in (2, 3, 4, 6, 8, 12)
                                               if x * 8 <= K_ // 64 and tiles * x <= 1024 and x * key[3] * M_ * N_ <= 16 * 2 ** 20)
                                         if tiles < 256 else ())
-                        if f.keywords.get("geglu"):
-                            sks = (1,)  # the GEGLU epilogues do not exist in the split-K reduce kernel
+                        if f.keywords.get("geglu") or h == 18:
+                            sks = (1,)  # the GEGLU epilogues do not exist in the split-K reduce kernel; tile 18 does not split
                         for sk in sks:
                             kw = dict(f.keywords)
                             kw["tile_hint"], kw["split_k"] = h, sk
