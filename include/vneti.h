@@ -75,8 +75,8 @@ typedef struct vneti_gemm_desc {
                          13 / 14 / 15: the same three tiles with a 4-stage ring (three stages in flight: short-K, latency-bound launches);
                          16 / 17: 256x256 / 256x128 as 8 waves in the 8-phase ping-pong structure (csrc/gemm8.hip; f16 out,
                          convs without fused upsampling; other launches fall back to 5 / 7);
-                         18: the halo-patch form of 17 for stride-1 pad-1 3x3 forward convolutions with chunk-major K
-                         (conv_korder 1) on a 16-pixel grid: a block owns 16 x 16 output pixels and keeps the 18 x 18 input
+                         18: the halo-patch form of 17 for stride-1 pad-1 3x3 convolutions (conv_mode 1, or 2 = the transposed
+                         gather of the input gradient) with chunk-major K (conv_korder 1) on a 16-pixel grid: a block owns 16 x 16 output pixels and keeps the 18 x 18 input
                          patch of a 64-channel chunk in LDS for all nine taps (bit-identical to 17; no split-K; other
                          launches fall back to 17);
                          +100 selects the register-staged (non LDS-DMA) reference variant */

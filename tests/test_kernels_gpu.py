@@ -330,7 +330,40 @@ def test_conv3x3_halo_tile(shape, epi):
         check("halo gn sumsq", got[..., 1].float(), (xg * xg).sum((1, 3)).float(), 1e-4)
 
 
-@pytest.mark.parametrize("hint", [3, 16, 17])
+@pytest.mark.parametrize("gate", [False, True], ids=["plain", "silu-gate"])
+@pytest.mark.parametrize("shape", [(2, 128, 64, 16, 32), (1, 192, 320, 32, 16)], ids=["2chunks", "3chunks-Ntail"])
+def test_conv3x3_dgrad_halo_tile(shape, gate):
+    """tile_hint 18 on the stride-1 transposed gather (the input gradient of the UNet's 3x3 convolutions; the tap (dy, dx)
+    reads patch pixel (y + 2 - dy, x + 2 - dx)): against autograd and bit for bit against tile 17; with the fused
+    activation-gradient gate of the GroupNorm-SiLU backward"""
+    ops = _ops()
+    from view_neti_amd import packing
+    Bn, Co, Ci, H, W = shape  # dy has Co channels, dx has Ci
+    x = rnd(Bn, Ci, H, W, seed=31).float().requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, scale=1 / math.sqrt(9 * Ci), seed=32)
+    y = F.conv2d(x, w.float(), None, padding=1)
+    dy = rnd(*y.shape, seed=33)
+    y.backward(dy.float())
+    ref = x.grad
+    M = Bn * H * W
+    kw = {}
+    if gate:
+        pre = rnd(M, Ci, seed=34)
+        s = torch.sigmoid(pre.float())
+        ref = ref * (s * (1 + pre.float() * (1 - s))).view(Bn, H, W, Ci).permute(0, 3, 1, 2)
+        kw.update(gate=pre.to(DEV), gate_act=1)
+    conv = dict(mode=2, Hi=H, Wi=W, Ci=Co, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Co, korder=1)
+    outs = {}
+    for hint in (17, 18):
+        dx = torch.zeros(M, Ci, dtype=torch.float16, device=DEV)
+        ops.gemm(_nhwc(dy).to(DEV), packing.conv3x3_dgrad(w, cm=True).to(DEV), dx, conv=conv, M=M, split_k=1, tile_hint=hint, **kw)
+        torch.cuda.synchronize()
+        outs[hint] = dx
+    check(f"conv dgrad halo {shape} gate={gate}", outs[18].view(Bn, H, W, Ci), _nhwc(ref), 3e-3)
+    assert torch.equal(outs[17], outs[18]), "tile 18 differs from tile 17"
+
+
+@pytest.mark.parametrize("hint", [3, 16, 17, 18])
 @pytest.mark.parametrize("korder", [0, 1], ids=["tap-major", "chunk-major"])
 @pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("stride,vae", [(1, False), (2, False), (2, True)])

@@ -29,7 +29,10 @@ for (B, H, W, Ci, Co) in CASES:
     w = packing.conv3x3_fwd(w4, cm=True).to(dev)
     bias = torch.randn(Co, device=dev)
     y = torch.empty(B * H * W, Co, device=dev, dtype=torch.float16)
-    conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci, korder=1)
+    mode = int(os.environ.get("MODE", "1"))  # 2: the stride-1 transposed gather (dgrad), same shapes
+    if mode == 2:
+        w = packing.conv3x3_dgrad(w4.permute(1, 0, 2, 3).contiguous(), cm=True).to(dev)
+    conv = dict(mode=mode, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci, korder=1)
     gf = 2.0 * B * H * W * Co * 9 * Ci / 1e9
     out, ref = [], None
     for h in (17, 18, 16):

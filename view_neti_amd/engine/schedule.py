@@ -181,8 +181,9 @@ class Schedule:
                     best, best_t = (0, 0, 0), float("inf")
                     M_, N_, K_ = key[:3]
                     # tile 18 = the halo-patch form of 17 (a block owns 16 x 16 pixels, the input patch stays in LDS for all
-                    # nine taps): stride-1 pad-1 3x3 forward convolutions on a 16-pixel grid, chunk-major K only, no split-K
-                    halo_ok = try_cm and conv["mode"] == 1 and conv["stride"] == 1 and conv["pad_t"] == 1 and conv["pad_l"] == 1 \
+                    # nine taps): stride-1 pad-1 3x3 convolutions (forward or transposed gather) on a 16-pixel grid, chunk-major K
+                    # only, no split-K
+                    halo_ok = try_cm and conv["mode"] in (1, 2) and conv["stride"] == 1 and conv["pad_t"] == 1 and conv["pad_l"] == 1 \
                         and conv["Ho"] % 16 == 0 and conv["Wo"] % 16 == 0 and conv["Hi"] == conv["Ho"] and conv["Wi"] == conv["Wo"]
                     variants = [(h, 0) for h in candidates if h != 18] + \
                         ([(h, 1) for h in candidates if h in (16, 17) or (h == 18 and halo_ok)] if try_cm else [])
