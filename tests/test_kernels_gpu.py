@@ -330,6 +330,29 @@ def test_conv3x3_halo_tile(shape, epi):
         check("halo gn sumsq", got[..., 1].float(), (xg * xg).sum((1, 3)).float(), 1e-4)
 
 
+@pytest.mark.parametrize("shape,split", [((1, 192, 320, 16, 32), 2), ((2, 256, 96, 32, 16), 3), ((1, 640, 128, 16, 16), 4)],
+                         ids=["3chunks/2", "4chunks/3", "10chunks/4"])
+def test_conv3x3_halo_tile_split_k(shape, split):
+    """tile 18 with split-K: the splits are rounded to whole 64-channel chunks (3 chunks / 2 -> 2 + 1, 4 / 3 -> 2 + 2,
+    10 / 4 -> 3 + 3 + 3 + 1); f32 partials + the reduce kernel's epilogue (bias, residual)"""
+    ops = _ops()
+    from view_neti_amd import packing
+    Bn, Ci, Co, H, W = shape
+    x = rnd(Bn, Ci, H, W, seed=41)
+    w = rnd(Co, Ci, 3, 3, scale=1 / math.sqrt(9 * Ci), seed=42)
+    bias = rnd(Co, seed=43, dtype=torch.float32)
+    M = Bn * H * W
+    res = rnd(M, Co, seed=44)
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1) + res.float().view(Bn, H, W, Co).permute(0, 3, 1, 2)
+    conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci, korder=1)
+    ws = torch.empty(split * M * Co, dtype=torch.float32, device=DEV)
+    out = torch.zeros(M, Co, dtype=torch.float16, device=DEV)
+    ops.gemm(_nhwc(x).to(DEV), packing.conv3x3_fwd(w, cm=True).to(DEV), out, bias=bias.to(DEV), resid=res.to(DEV), conv=conv, M=M,
+             tile_hint=18, split_k=split, workspace=ws)
+    torch.cuda.synchronize()
+    check(f"conv halo split {shape} /{split}", out.view(Bn, H, W, Co), _nhwc(ref), 3e-3)
+
+
 @pytest.mark.parametrize("gate", [False, True], ids=["plain", "silu-gate"])
 @pytest.mark.parametrize("shape", [(2, 128, 64, 16, 32), (1, 192, 320, 32, 16)], ids=["2chunks", "3chunks-Ntail"])
 def test_conv3x3_dgrad_halo_tile(shape, gate):

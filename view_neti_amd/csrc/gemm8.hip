@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   if constexpr (HALO) {
     constexpr int BRING = 2 * PATCH_STRIDE;   // the B tiles live behind the two patch slots
     constexpr int PROW = 18 * 128;            // bytes per patch row (18 pixels x 64 channels)
-    const int nchunk = g.Ci >> 6;
+    const int c_begin = kt_begin / 9, c_end = kt_end / 9;  // this split's channel chunks (the launcher aligns splits to chunks)
     // ---- patch staging: wave-DMA number d = 8j + wave (d < 41) covers the 64 consecutive 16-byte slots q = 64d + lane of
     // a patch slot; slot q = pixel p = q / 8 (row-major in the 18 x 18 patch), physical chunk q % 8, which holds the logical
     // chunk (q % 8) ^ ((px >> 1) & 7) — a 16-lane fragment read walks 16 consecutive px of one patch row, so keying the
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     {
       constexpr int BBUF = 2 * HB_BYTES;  // 16 KiB per K-tile, ring of three
       auto issueBt = [&](const int kt, const int buf) {  // both 64-column halves of K-tile kt
-        const uint32_t soff = (uint32_t)kt * 128u, dead = kt < T ? 0u : VN_OOB;
+        const uint32_t soff = (uint32_t)(kt_begin + kt) * 128u, dead = kt < T ? 0u : VN_OOB;
         char* dst = smem + BRING + buf * BBUF + wave * 1024;
         if (!(VN_GEMM8_LAB & 4)) {
           dma16(rsB, dst, (b_base[0] + soff) | dead);
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       // ---- prologue: the whole patch of chunk 0, B tiles 0 and 1 ----
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        if (j < np_wave) issueP(j, 0);
+        if (j < np_wave) issueP(j, c_begin);
       issueBt(0, 0);
       issueBt(1, 1);
       VN_WAIT_VM(2);  // patch 0 and B tile 0 have landed
@@ -506,11 +506,11 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       // patch at taps 1..6: its slot was last read in Q1 of the previous chunk's tap 8, three phases before]; Q1 reads the
       // other two tile rows [4] and waits for B(t + 1) (read in the next Q0): everything but this tile's stagings, which
       // come later in the stream.
-      int c = 0, tap = 0, rbuf = 0, sbuf = 2;
+      int c = c_begin, tap = 0, rbuf = 0, sbuf = 2;
       for (int t = 0; t < T; ++t) {
         const int dy = tap_dy(tap), dx = tap_dx(tap);
         const int ab = (dx == 0 ? lb[0] : (dx == 1 ? lb[1] : lb[2])) + (c & 1) * PATCH_STRIDE + dy * PROW;
-        const bool stage_p = tap >= 1 && tap <= np_wave && c + 1 < nchunk;
+        const bool stage_p = tap >= 1 && tap <= np_wave && c + 1 < c_end;
         // Q0
         readBh(rbuf);
         readAh(0, ab);
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 
   // acc[h][j][i][jb][e]  <->  block row h*128 + wr*64 + i*16 + frow, block column j*(BN/2) + wc*16*NJB + jb*16 + 4*fq + e
   // ---- split-K: raw f32 partials straight to the workspace ----
-  if (!HALO && g.ksplit > 1) {
+  if (g.ksplit > 1) {
     float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -672,8 +672,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int jb = 0; jb < NJB; ++jb) {
-            const int m = m0 + h * 128 + wr * 64 + i * 16 + frow;
-            const int n = n0 + j * (BN / 2) + wc * (16 * NJB) + jb * 16 + 4 * fq;
+            const int m = rowmem(acc_row(h, i));
+            const int n = n0 + acc_col(h, j, jb);
             if (m < g.M && n < g.N) {
               float* p = ws + (long long)m * g.N + n;
               if (n + 4 <= g.N && (g.N & 3) == 0) {
@@ -921,16 +921,21 @@ inline int epilogue_level8(const GemmArgs& g) {
 // f16 output only; the caller (vneti_gemm_f16) has validated the descriptor, set ksplit / kt_per_split and launches the
 // split-K reduce itself.  Returns VNETI_EUNSUP for what the requested tile does not carry (f32 output, fused upsample,
 // stride-2 transposed gather; halo: anything but a stride-1 pad-1 3x3 convolution (forward or transposed gather) on a
-// 16-pixel grid with chunk-major K and no split).
+// 16-pixel grid with chunk-major K; its split-K splits are rounded to whole channel chunks).
 int vneti_launch_gemm8(void* gemm_args, int bn, int halo, hipStream_t st) {
   GemmArgs& g = *reinterpret_cast<GemmArgs*>(gemm_args);
   if (g.out_f32 || (g.conv_mode && (g.ups || (g.conv_mode == 2 && g.stride == 2))) ||
       (g.M >= (1 << 24) && (g.conv_mode || g.rowadd || g.gn_sums)))  // float-reciprocal row arithmetic: rows < 2^24
     return VNETI_EUNSUP;
   if (halo && (bn != 128 || g.conv_mode < 1 || g.conv_mode > 2 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.Hi != g.Ho ||
-               g.Wi != g.Wo || (g.Ho & 15) || (g.Wo & 15) || (g.Ci & 63) || g.K != 9 * g.Ci || !g.korder || g.ksplit != 1 ||
+               g.Wi != g.Wo || (g.Ho & 15) || (g.Wo & 15) || (g.Ci & 63) || g.K != 9 * g.Ci || !g.korder ||
                g.batch != 1 || g.M != (g.M / (g.Ho * g.Wo)) * g.Ho * g.Wo))
     return VNETI_EUNSUP;
+  if (halo && g.ksplit > 1) {  // splits own whole 64-channel chunks (nine K-tiles each): the patch logic stays per chunk
+    const int nchunk = g.Ci / 64, cps = cdiv(nchunk, g.ksplit);
+    g.kt_per_split = 9 * cps;
+    g.ksplit = cdiv(nchunk, cps);
+  }
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, bn);
   const dim3 grid(g.tiles_m * g.tiles_n, g.batch, g.ksplit), block(NT);

@@ -910,11 +910,10 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   // the 8-phase tile: LDS-DMA only; convolutions whose gather offset is linear in the tap (no fused upsample, no
   // stride-2 transposed gather), tap-major K order
   // the halo-patch form of the 256x128 8-phase tile: stride-1 pad-1 3x3 convolutions (forward or transposed gather) on a
-  // 16-pixel grid, chunk-major K, no split-K; anything else runs as the row-major tile
+  // 16-pixel grid, chunk-major K (split-K in whole channel chunks); anything else runs as the row-major tile
   if (cfg == 18 &&
       (d->conv_mode < 1 || d->conv_mode > 2 || d->stride != 1 || d->ups || d->pad_t != 1 || d->pad_l != 1 || d->Hi != d->Ho ||
-       d->Wi != d->Wo || (d->Ho & 15) || (d->Wo & 15) || (d->Ci & 63) || !d->conv_korder || batch != 1 || f32 ||
-       (d->split_k != 1 && d->split_k != 0)))
+       d->Wi != d->Wo || (d->Ho & 15) || (d->Wo & 15) || (d->Ci & 63) || !d->conv_korder || batch != 1 || f32))
     cfg = 17;
   if ((cfg == 16 || cfg == 17) && (!dma || (d->conv_mode && (d->ups || (d->conv_mode == 2 && d->stride == 2))) ||
                     (d->M >= (1 << 24) && (d->conv_mode || d->rowadd || d->gn_sums)))) cfg = cfg == 16 ? 5 : 7;
@@ -934,7 +933,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     VN_REQUIRE(batch == 1 || (d->strideC != 0), "gemm: batched split-K needs strideC");
     VN_REQUIRE((long long)batch * d->M * ((d->N + 3) / 4) < 0x7fffffffLL, "gemm: split-K output larger than 2^31 chunks");
   }
-  if (cfg == 18 && ks > 1) cfg = 17;  // (the heuristic chose to split: the halo form does not)
+  if (cfg == 18 && ks > d->Ci / 64) ks = d->Ci / 64;  // the halo form splits in whole 64-channel chunks
   g.ksplit = ks;
   g.kt_per_split = cdiv(nk, ks);
   g.ksplit = cdiv(nk, g.kt_per_split);  // drop empty trailing splits

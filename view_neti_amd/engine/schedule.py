@@ -182,7 +182,7 @@ class Schedule:
                     M_, N_, K_ = key[:3]
                     # tile 18 = the halo-patch form of 17 (a block owns 16 x 16 pixels, the input patch stays in LDS for all
                     # nine taps): stride-1 pad-1 3x3 convolutions (forward or transposed gather) on a 16-pixel grid, chunk-major K
-                    # only, no split-K
+                    # only; split-K in whole channel chunks
                     halo_ok = try_cm and conv["mode"] in (1, 2) and conv["stride"] == 1 and conv["pad_t"] == 1 and conv["pad_l"] == 1 \
                         and conv["Ho"] % 16 == 0 and conv["Wo"] % 16 == 0 and conv["Hi"] == conv["Ho"] and conv["Wi"] == conv["Wo"]
                     variants = [(h, 0) for h in candidates if h != 18] + \
@@ -196,8 +196,8 @@ class Schedule:
                         sks = (0, 1) + (tuple(x for x in (2, 3, 4, 6, 8, 12)
                                               if x * 8 <= K_ // 64 and tiles * x <= 1024 and x * key[3] * M_ * N_ <= 16 * 2 ** 20)
                                         if tiles < 256 else ())
-                        if f.keywords.get("geglu") or h == 18:
-                            sks = (1,)  # the GEGLU epilogues do not exist in the split-K reduce kernel; tile 18 does not split
+                        if f.keywords.get("geglu"):
+                            sks = (1,)  # the GEGLU epilogues do not exist in the split-K reduce kernel
                         for sk in sks:
                             kw = dict(f.keywords)
                             kw["tile_hint"], kw["split_k"] = h, sk
