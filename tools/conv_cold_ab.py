@@ -7,7 +7,7 @@ from view_neti_amd import ops
 dev = "cuda"
 ws = torch.empty(64 * 2 ** 20, dtype=torch.float32, device=dev)
 cold = torch.empty(160 * 2 ** 20, dtype=torch.float32, device=dev)
-for (B, H, W, Ci, Co) in [(4, 512, 512, 128, 128), (4, 256, 256, 256, 256), (4, 256, 256, 128, 256), (4, 64, 64, 320, 320), (4, 64, 64, 640, 320)]:
+for (B, H, W, Ci, Co) in [(4, 512, 512, 128, 128), (4, 256, 256, 256, 256), (4, 256, 256, 128, 256), (4, 128, 128, 512, 512)]:
     x = torch.randn(B * H * W, Ci, device=dev).half()
     w = (torch.randn(Co, 9 * Ci, device=dev) * 0.03).half()
     bias = torch.randn(Co, device=dev)
@@ -18,7 +18,7 @@ for (B, H, W, Ci, Co) in [(4, 512, 512, 128, 128), (4, 256, 256, 256, 256), (4, 
     out = []
     from view_neti_amd import packing
     w4 = (torch.randn(Co, Ci, 3, 3) * 0.03).half()
-    for h, ko in ((5, 0), (7, 0), (9, 0), (16, 0), (17, 0), (16, 1), (17, 1), (5, 1), (7, 1)):
+    for h, ko in ((7, 0), (16, 0), (17, 0), (16, 1), (17, 1), (18, 1)):
         w = packing.conv3x3_fwd(w4, cm=bool(ko)).to(dev)
         conv["korder"] = ko
         ts = []

@@ -43,6 +43,6 @@ for (B, H, W, Ci, Co) in CASES:
             ref = y.clone()
             tag = ""
         else:
-            tag = " (== 17)" if torch.equal(y, ref) else f" (max |d| {(y.float() - ref.float()).abs().max().item():.3e} !!)"
+            tag = " (== 17)" if torch.equal(y, ref) else f" (rel {((y.float() - ref.float()).norm() / ref.float().norm()).item():.1e}, max |d| {(y.float() - ref.float()).abs().max().item():.1e})"
         out.append(f"h{h} {t:7.1f}us {gf / t * 1e3:5.0f}TF{tag}")
     print(f"conv {B}x{H}x{W} {Ci}->{Co} {gf:6.1f}GF: " + "  ".join(out), flush=True)

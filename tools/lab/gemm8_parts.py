@@ -38,12 +38,13 @@ ws = torch.empty(64 * 2 ** 20, dtype=torch.float32, device=dev)
 out = []
 CASES = [(4, 512, 512, 128, 128, 17), (4, 256, 256, 256, 256, 16), (4, 64, 64, 640, 640, 16)]
 if os.environ.get("HALO"):  # the halo-patch form (tile 18, chunk-major K; random weights, the order does not matter here)
-    CASES = [(4, 512, 512, 128, 128, 18), (4, 128, 128, 512, 512, 18), (4, 64, 64, 640, 640, 18)]
+    hh = int(os.environ.get("HINT", "18"))  # 19: the 512x128 form
+    CASES = [(4, 512, 512, 128, 128, hh), (4, 128, 128, 512, 512, hh), (4, 64, 64, 640, 640, hh)]
 for (B, H, W, Ci, Co, hint) in CASES:
     x = torch.randn(B * H * W, Ci, device=dev).half()
     w = (torch.randn(Co, 9 * Ci, device=dev) * 0.03).half()
     y = torch.empty(B * H * W, Co, device=dev, dtype=torch.float16)
-    conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci, korder=1 if hint == 18 else 0)
+    conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci, korder=1 if hint >= 18 else 0)
     f = lambda: ops.gemm(x, w, y, M=B * H * W, conv=conv, tile_hint=hint, workspace=ws, split_k=1)
     for _ in range(3): f()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
