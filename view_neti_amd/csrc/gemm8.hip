@@ -477,7 +477,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #define VN_MMA4(HALF)                                                                                          \
   do {                                                                                                         \
     VN_WAIT_LGKM0();                                                                                           \
-    __builtin_amdgcn_s_setprio(1);                                                                             \
+    if (!(VN_GEMM8_LAB & 32)) __builtin_amdgcn_s_setprio(1);                                                   \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 2 * HALF; i < 2 * HALF + 2; ++i) \
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                     \
       if (VN_GEMM8_LAB & 1) {                                                                                  \
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
             __builtin_amdgcn_mfma_f32_16x16x32_f16(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0); \
       }                                                                                                        \
     }                                                                                                          \
-    __builtin_amdgcn_s_setprio(0);                                                                             \
+    if (!(VN_GEMM8_LAB & 32)) __builtin_amdgcn_s_setprio(0);                                                   \
   } while (0)
       // ---- prologue: the whole patch of chunk 0, B tiles 0 and 1 ----
 #pragma unroll
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       VN_STAMP(1);
-      if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+      if (wr == 1 && !(VN_GEMM8_LAB & 128)) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
       __builtin_amdgcn_sched_barrier(0);
       // K-tile t = (chunk c, tap): Q0 reads the wave's four column blocks of B(t) and two of its four tile rows at the
       // tap's offset [12 ds_read_b128], stages B(t + 2) [its buffer was last read in Q0(t - 1)] [+ one DMA of chunk c + 1's
@@ -518,6 +518,15 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         issueBt(t + 2, sbuf);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (VN_GEMM8_LAB & 64) {  // (lab: one phase of 32 MFMAs per K-tile, every read up front)
+          readAh(1, ab);
+          VN_WAIT_VM(2);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          VN_MMA4(0);
+          VN_MMA4(1);
+          VN_PHASE_END();
+        } else {
         VN_MMA4(0);
         VN_PHASE_END();
         // Q1
@@ -529,6 +538,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         }
         VN_MMA4(1);
         VN_PHASE_END();
+        }
         tap += 1;
         if (tap == 9) {
           tap = 0;
@@ -653,7 +663,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #undef VN_SYNC
   }
   VN_STAMP(2);
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+  if (wr == 0 && !(HALO && (VN_GEMM8_LAB & 128))) __builtin_amdgcn_s_barrier();  // balance the stagger
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the (zero-filling) stagings past the end must have landed
   __syncthreads();                                                // before the epilogue reuses the buffers as its C tile
 #undef VN_MMA
