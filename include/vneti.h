@@ -244,6 +244,14 @@ int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* K, long long ld
 /* ws (optional f32 scratch): when the key side is short (cross-attention, Nk = 77) the query
  * range is split across workgroups and the f32 partials are reduced by a second kernel;
  * needs 2*qsplit*Bn*Nk*H*D floats (qsplit <= 32), NULL disables the split. */
+/* dQ, dK and dV of a short self-attention in ONE launch: N <= 96 and D = 64 (the 77-token CLIP text encoder that
+ * training/coach.py:289-305 runs once per UNet cross-attention layer, models/neti_clip_text_encoder.py:90-118), one
+ * workgroup per (sequence, head) with Q, K, V, dO in LDS; bit-identical to vneti_attn_bwd_dq (O given) followed by
+ * vneti_attn_bwd_dkv.  Returns VNETI unsupported (-2) for other sizes: the caller then uses the two kernels above. */
+int vneti_attn_bwd_small(const void* Q, long long ldq, const void* K, long long ldk, const void* V, long long ldv,
+                         const void* dO, long long lddo, const void* O, long long ldo, const float* lse, void* dQ,
+                         long long lddq, void* dK, long long lddk, void* dV, long long lddv, int Bn, int H, int N, int D,
+                         float scale, int causal, void* stream);
 /* row softmax in place on f16 [rows][ld] (unfused attention of the VAE mid-block, d=512) */
 int vneti_softmax_rows_f16(void* x, long long ld, int rows, int cols, void* stream);
 

@@ -624,6 +624,43 @@ def test_attention_fwd_bwd(D, H, Nq, Nk, causal):
     check(f"attn dv {tag}", dv.view(Bn, Nk, Cc), vr.grad, 6e-3)
 
 
+@pytest.mark.parametrize("H,N,causal", [(12, 77, True), (16, 77, True), (3, 96, True), (2, 33, True), (4, 77, False), (5, 64, False)])
+def test_attention_bwd_small_fused(H, N, causal):
+    """vneti_attn_bwd_small (the CLIP text encoder's 77-token, 64-wide-head attention: dQ, dK, dV of a (sequence, head) in one
+    launch) against autograd and, bit for bit, against the dQ + dK/dV kernel pair it replaces; strided q / k / v views
+    of one fused qkv buffer as the text engine passes them"""
+    ops = _ops()
+    D, Bn = 64, 3
+    Cc = H * D
+    scale = D ** -0.5
+    qkv = rnd(Bn * N, 3 * Cc, seed=61)
+    do = rnd(Bn, N, Cc, seed=62)
+    q, k, v = (qkv[:, i * Cc:(i + 1) * Cc].reshape(Bn, N, Cc) for i in range(3))
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = _attn_ref(qr, kr, vr, H, D, scale, causal)
+    o_ref.backward(do.float())
+    qkv_d = qkv.to(DEV)
+    qd, kd, vd = qkv_d[:, :Cc], qkv_d[:, Cc:2 * Cc], qkv_d[:, 2 * Cc:]
+    dod = do.to(DEV).view(-1, Cc)
+    o = torch.zeros(Bn * N, Cc, dtype=torch.float16, device=DEV)
+    lse = torch.zeros(Bn, H, N, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(qd, kd, vd, o, lse, Bn, H, N, N, D, scale, causal)
+    delta = torch.zeros(Bn, H, N, dtype=torch.float32, device=DEV)
+    dqkv = [torch.full((Bn * N, 3 * Cc), float("nan"), dtype=torch.float16, device=DEV) for _ in range(2)]
+    dq, dk, dv = dqkv[0][:, :Cc], dqkv[0][:, Cc:2 * Cc], dqkv[0][:, 2 * Cc:]
+    ops.attn_bwd_dq(qd, kd, vd, dod, lse, delta, dq, Bn, H, N, N, D, scale, causal, O=o)
+    ops.attn_bwd_dkv(qd, kd, vd, dod, lse, delta, dk, dv, Bn, H, N, N, D, scale, causal)
+    assert ops.attn_bwd_small_ok(N, D)
+    dq2, dk2, dv2 = dqkv[1][:, :Cc], dqkv[1][:, Cc:2 * Cc], dqkv[1][:, 2 * Cc:]
+    ops.attn_bwd_small(qd, kd, vd, dod, o, lse, dq2, dk2, dv2, Bn, H, N, D, scale, causal)
+    torch.cuda.synchronize()
+    tag = f"H{H} N{N} c{int(causal)}"
+    check(f"attn small dq {tag}", dq2.reshape(Bn, N, Cc), qr.grad, 6e-3)
+    check(f"attn small dk {tag}", dk2.reshape(Bn, N, Cc), kr.grad, 6e-3)
+    check(f"attn small dv {tag}", dv2.reshape(Bn, N, Cc), vr.grad, 6e-3)
+    assert torch.equal(dqkv[0], dqkv[1]), "fused small backward differs from the dQ + dK/dV pair"
+
+
 def test_vae_single_head_attention_d512():
     """the VAE mid block's attention (one head of dim C = 512 over N = h*w tokens) as the engine issues it: batched
     q.k^T GEMM with alpha = C^-1/2 into an [N, ld] score matrix, softmax_rows in place, v transposed, P.v GEMM — vs

@@ -751,6 +751,240 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnA
   }
 }
 
+// ============================================================================================
+// backward for short sequences (Nq = Nk <= 96: the 77 tokens of the CLIP text encoder, 64 x 12 (sequence, head) pairs per
+// step): one block per (sequence, head) keeps Q, K, V, dO of the head in LDS and produces dQ, dK and dV in ONE launch —
+// the dQ and dK/dV kernels above are each a ~15-20 us latency chain at this size (zero-fill, global loads, two staged
+// tiles, epilogue) for 0.1 GFLOP.  Wave w owns rows 32w..32w+31 twice: as queries (the dQ body above over the key blocks,
+// computing delta on the way) and, after a barrier, as keys (the dK/dV body over the query blocks).  Same arithmetic per
+// element as the separate kernels (S recomputed in both roles), so results are bit-identical to them.
+// ============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(AttnArgs a) {
+  using C = Cfg<D>;
+  constexpr int NR = 96;
+  constexpr int TILE = NR * C::ROW + 128;  // row-major [row][d] (+ slack: the transposed reads touch the d-padding)
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE + 2 * NR * 4];
+  char* Qs = smem;
+  char* Ks = smem + TILE;
+  char* Vs = smem + 2 * TILE;
+  char* dOs = smem + 3 * TILE;
+  float* lses = reinterpret_cast<float*>(smem + 4 * TILE);
+  float* dels = lses + NR;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int N = a.Nq;
+
+  __amdgpu_buffer_rsrc_t rsQ = vn_make_rsrc(a.Q, (uint32_t)((long long)a.Bn * N * a.ldq * 2));
+  __amdgpu_buffer_rsrc_t rsdO = vn_make_rsrc(a.dO, (uint32_t)((long long)a.Bn * N * a.lddo * 2));
+  __amdgpu_buffer_rsrc_t rsK = vn_make_rsrc(a.K, (uint32_t)((long long)a.Bn * N * a.ldk * 2));
+  __amdgpu_buffer_rsrc_t rsV = vn_make_rsrc(a.V, (uint32_t)((long long)a.Bn * N * a.ldv * 2));
+  __amdgpu_buffer_rsrc_t rsO = vn_make_rsrc(a.O_in, (uint32_t)((long long)a.Bn * N * a.ldo * 2));
+
+  // ---- the four operand tiles: requested first, stored after the zero-fill (pad rows and the d-padding stay zero) ----
+  constexpr int NIT = (NR * C::DCH + 255) / 256;
+  u32x4 rq[NIT], rk[NIT], rv[NIT], rd[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx / C::DCH, cc = idx - r * C::DCH;
+    const bool ok = idx < NR * C::DCH && r < N;
+    const long long row = (long long)b * N + r;
+    rq[i] = vn_buf_load16(rsQ, ok ? (uint32_t)((row * a.ldq + h * D + cc * 8) * 2) : VN_OOB);
+    rk[i] = vn_buf_load16(rsK, ok ? (uint32_t)((row * a.ldk + h * D + cc * 8) * 2) : VN_OOB);
+    rv[i] = vn_buf_load16(rsV, ok ? (uint32_t)((row * a.ldv + h * D + cc * 8) * 2) : VN_OOB);
+    rd[i] = vn_buf_load16(rsdO, ok ? (uint32_t)((row * a.lddo + h * D + cc * 8) * 2) : VN_OOB);
+  }
+  float lreg = INFINITY;
+  if (tid < NR && tid < N) lreg = a.lse_in[((long long)b * a.H + h) * N + tid] * LOG2E;
+  zero_lds(smem, 4 * TILE);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx / C::DCH, cc = idx - r * C::DCH;
+    if (idx < NR * C::DCH) {
+      *reinterpret_cast<u32x4*>(Qs + r * C::ROW + cc * 16) = rq[i];
+      *reinterpret_cast<u32x4*>(Ks + r * C::ROW + cc * 16) = rk[i];
+      *reinterpret_cast<u32x4*>(Vs + r * C::ROW + cc * 16) = rv[i];
+      *reinterpret_cast<u32x4*>(dOs + r * C::ROW + cc * 16) = rd[i];
+    }
+  }
+  if (tid < NR) lses[tid] = lreg;
+  __syncthreads();
+
+  const float c = a.scale * LOG2E;
+  const int row = wave * 32 + l31;  // this lane's query (first role) / key (second role)
+  const bool rok = row < N;
+  // ---- role 1: dQ of queries 32w..32w+31 (attn_dq_kernel's body over 32-key blocks) ----
+  if (wave < 3) {
+    half8 qf[C::KS], dof[C::KS];
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int ch = ks * 2 + h2;
+      qf[ks] = as_half8(*reinterpret_cast<const u32x4*>(Qs + row * C::ROW + ch * 16));
+      dof[ks] = as_half8(*reinterpret_cast<const u32x4*>(dOs + row * C::ROW + ch * 16));
+      const uint32_t offo = (rok && ch < C::DCH) ? (uint32_t)((((long long)b * N + row) * a.ldo + h * D + ch * 8) * 2) : VN_OOB;
+      const half8 of = as_half8(vn_buf_load16(rsO, offo));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += (float)dof[ks][j] * (float)of[j];
+    }
+    const float dlt = part + __shfl_xor(part, 32, 64);  // delta[q] = sum_d dO[q][d] * O[q][d]
+    if (h2 == 0) dels[row] = dlt;
+    const float lse2 = lses[row];
+    f32x16 dq[C::DB];
+#pragma unroll
+    for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
+    const int nkb = a.causal ? wave + 1 : 3;
+    for (int aa = 0; aa < nkb; ++aa) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s[e] = 0.f;
+        dp[e] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const int off = (aa * 32 + l31) * C::ROW + (ks * 2 + h2) * 16;
+        half8 kf = as_half8(*reinterpret_cast<const u32x4*>(Ks + off));
+        half8 vf = as_half8(*reinterpret_cast<const u32x4*>(Vs + off));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
+      }
+      if (aa * 32 + 32 > N || (a.causal && aa == wave)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = aa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          const bool ok = key < N && (!a.causal || key <= row);
+          if (!ok) s[r] = -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{c, c}, f32x2{-lse2, -lse2});
+        const f32x2 g = f32x2{dp[r], dp[r + 1]} - f32x2{dlt, dlt};
+        const f32x2 ds = f32x2{fast_exp2(t.x), fast_exp2(t.y)} * g;
+        s[r] = ds.x;
+        s[r + 1] = ds.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        half8 pf = cvt8(s, j);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+          half8 tf = load_tr(Ks, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, pf, dq[db], 0, 0, 0);
+        }
+      }
+    }
+    if (rok) {
+      half_t* orow = a.dQ + ((long long)b * N + row) * a.lddq + h * D;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int d = db * 32 + 8 * qd + 4 * h2;
+          if (d < D) {
+            half4 v = {(half_t)(dq[db][4 * qd] * a.scale), (half_t)(dq[db][4 * qd + 1] * a.scale),
+                       (half_t)(dq[db][4 * qd + 2] * a.scale), (half_t)(dq[db][4 * qd + 3] * a.scale)};
+            *reinterpret_cast<half4*>(orow + d) = v;
+          }
+        }
+    }
+  }
+  __syncthreads();  // every query's delta is in LDS
+  // ---- role 2: dK, dV of keys 32w..32w+31 (attn_dkv_kernel's body over 32-query blocks) ----
+  if (wave < 3) {
+    half8 kf[C::KS], vf[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int ch = ks * 2 + h2;
+      kf[ks] = as_half8(*reinterpret_cast<const u32x4*>(Ks + row * C::ROW + ch * 16));
+      vf[ks] = as_half8(*reinterpret_cast<const u32x4*>(Vs + row * C::ROW + ch * 16));
+    }
+    f32x16 dk[C::DB], dv[C::DB];
+#pragma unroll
+    for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        dk[i][e] = 0.f;
+        dv[i][e] = 0.f;
+      }
+    for (int hq = a.causal ? wave : 0; hq < 3; ++hq) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s[e] = 0.f;
+        dp[e] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const int off = (hq * 32 + l31) * C::ROW + (ks * 2 + h2) * 16;
+        half8 qfr = as_half8(*reinterpret_cast<const u32x4*>(Qs + off));
+        half8 dofr = as_half8(*reinterpret_cast<const u32x4*>(dOs + off));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dofr, vf[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 l4 = *reinterpret_cast<const f32x4*>(&lses[hq * 32 + 8 * qd + 4 * h2]);
+        f32x4 d4 = *reinterpret_cast<const f32x4*>(&dels[hq * 32 + 8 * qd + 4 * h2]);
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const int r = 4 * qd + e;
+          const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{c, c}, -f32x2{l4[e], l4[e + 1]});
+          f32x2 p = f32x2{fast_exp2(t.x), fast_exp2(t.y)};
+          if (a.causal) {
+            const int qq = hq * 32 + 8 * qd + 4 * h2 + e;
+            if (row > qq) p.x = 0.f;
+            if (row > qq + 1) p.y = 0.f;
+          }
+          const f32x2 ds = p * (f32x2{dp[r], dp[r + 1]} - f32x2{d4[e], d4[e + 1]});
+          s[r] = p.x;
+          s[r + 1] = p.y;
+          dp[r] = ds.x;
+          dp[r + 1] = ds.y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        half8 pf = cvt8(s, j);
+        half8 dsf = cvt8(dp, j);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+          half8 dot = load_tr(dOs, C::ROW, db * 32, hq * 32 + 16 * j + 4 * h2, lane);
+          half8 qtf = load_tr(Qs, C::ROW, db * 32, hq * 32 + 16 * j + 4 * h2, lane);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf, dk[db], 0, 0, 0);
+        }
+      }
+    }
+    if (rok) {
+      half_t* krow = a.dK + ((long long)b * N + row) * a.lddk + h * D;
+      half_t* vrow = a.dV + ((long long)b * N + row) * a.lddv + h * D;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int d = db * 32 + 8 * qd + 4 * h2;
+          if (d < D) {
+            half4 k4 = {(half_t)(dk[db][4 * qd] * a.scale), (half_t)(dk[db][4 * qd + 1] * a.scale),
+                        (half_t)(dk[db][4 * qd + 2] * a.scale), (half_t)(dk[db][4 * qd + 3] * a.scale)};
+            half4 v4 = {(half_t)dv[db][4 * qd], (half_t)dv[db][4 * qd + 1], (half_t)dv[db][4 * qd + 2],
+                        (half_t)dv[db][4 * qd + 3]};
+            *reinterpret_cast<half4*>(krow + d) = k4;
+            *reinterpret_cast<half4*>(vrow + d) = v4;
+          }
+        }
+    }
+  }
+}
+
 // sum the q-split partials of the dK/dV kernel, apply the softmax scale to dK, round to f16
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs a) {
   const int Cc = a.H * a.D;
@@ -938,4 +1172,43 @@ extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* K, l
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdivl(n4, 256)), dim3(256), 0, st, a);
   }
   return vneti_check_launch("attn_bwd_dkv");
+}
+
+extern "C" int vneti_attn_bwd_small(const void* Q, long long ldq, const void* K, long long ldk, const void* V, long long ldv,
+                                    const void* dO, long long lddo, const void* O, long long ldo, const float* lse, void* dQ,
+                                    long long lddq, void* dK, long long lddk, void* dV, long long lddv, int Bn, int H, int N,
+                                    int D, float scale, int causal, void* stream) {
+  VN_REQUIRE(Q && K && V && dO && O && lse && dQ && dK && dV, "attn_bwd_small: null pointer");
+  VN_REQUIRE(Bn > 0 && H > 0 && N > 0, "attn_bwd_small: bad shape B=%d H=%d N=%d", Bn, H, N);
+  if (N > 96 || D != 64) return VNETI_EUNSUP;  // longer sequences / other head sizes: vneti_attn_bwd_dq + vneti_attn_bwd_dkv
+  VN_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 &&
+                 lddv % 4 == 0, "attn_bwd_small: bad strides");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const half_t*)Q;
+  a.K = (const half_t*)K;
+  a.V = (const half_t*)V;
+  a.dO = (const half_t*)dO;
+  a.O_in = (const half_t*)O;
+  a.lse_in = lse;
+  a.dQ = (half_t*)dQ;
+  a.dK = (half_t*)dK;
+  a.dV = (half_t*)dV;
+  a.ldq = ldq;
+  a.ldk = ldk;
+  a.ldv = ldv;
+  a.lddo = lddo;
+  a.ldo = ldo;
+  a.lddq = lddq;
+  a.lddk = lddk;
+  a.lddv = lddv;
+  a.Bn = Bn;
+  a.H = H;
+  a.Nq = N;
+  a.Nk = N;
+  a.D = D;
+  a.scale = scale;
+  a.causal = causal;
+  hipLaunchKernelGGL((attn_bwd_small_kernel<64>), dim3(H, Bn), dim3(256), 0, (hipStream_t)stream, a);
+  return vneti_check_launch("attn_bwd_small");
 }

@@ -331,9 +331,12 @@ class TextEngine(Schedule):
             dqkv = self._tmp("cE", Rt, 3 * D)
             dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
             sc_ = hd ** -0.5
-            # dQ first: it also produces delta = rowsum(dO o O) for the dK/dV kernel
-            bw.append(partial(ops.attn_bwd_dq, q, k, v, do, r["lse"], delta, dq, R, H, L, L, hd, sc_, True, O=r["o"]))
-            bw.append(partial(ops.attn_bwd_dkv, q, k, v, do, r["lse"], delta, dk, dv, R, H, L, L, hd, sc_, True))
+            if ops.attn_bwd_small_ok(L, hd):  # 77 tokens, 64-wide heads: dQ, dK, dV of a (sequence, head) in one launch
+                bw.append(partial(ops.attn_bwd_small, q, k, v, do, r["o"], r["lse"], dq, dk, dv, R, H, L, hd, sc_, True))
+            else:
+                # dQ first: it also produces delta = rowsum(dO o O) for the dK/dV kernel
+                bw.append(partial(ops.attn_bwd_dq, q, k, v, do, r["lse"], delta, dq, R, H, L, L, hd, sc_, True, O=r["o"]))
+                bw.append(partial(ops.attn_bwd_dkv, q, k, v, do, r["lse"], delta, dk, dv, R, H, L, L, hd, sc_, True))
             dn1 = self._tmp("cC", Rt, D)
             bw.append(partial(ops.gemm, dqkv, r["wqkvd"], dn1))
             bw.append(partial(self._ln_bwd, r["ln1"], dn1, dx, dxm, g16))     # dx_in = LN1'(dn1) + dx_mid

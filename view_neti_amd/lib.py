@@ -147,6 +147,8 @@ SIGNATURES = {
                     c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
     "attn_bwd_dkv": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp,
                      c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_f, c_int, c_vp, c_ll, c_vp],
+    "attn_bwd_small": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp, c_ll,
+                       c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
     "softmax_rows_f16": [c_vp, c_ll, c_int, c_int, c_vp],
     "add_f16": [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_vp],
     "geglu_fwd": [c_vp, c_ll, c_vp, c_ll, c_int, c_int, c_vp],

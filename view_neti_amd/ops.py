@@ -196,6 +196,17 @@ def attn_bwd_dkv(Q, K, V, dO, lse, delta, dK, dV, Bn, H, Nq, Nk, D, scale, causa
             ws.numel() if ws is not None else 0, stream())
 
 
+def attn_bwd_small_ok(N, D):
+    """sizes vneti_attn_bwd_small carries (the caller picks between it and attn_bwd_dq + attn_bwd_dkv)"""
+    return N <= 96 and D == 64
+
+
+def attn_bwd_small(Q, K, V, dO, O, lse, dQ, dK, dV, Bn, H, N, D, scale, causal):
+    """dQ, dK, dV of a short self-attention (N <= 96, D = 64) in one launch"""
+    _l.call("attn_bwd_small", _p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO), _p(O), _ld(O), _p(lse),
+            _p(dQ), _ld(dQ), _p(dK), _ld(dK), _p(dV), _ld(dV), Bn, H, N, D, scale, 1 if causal else 0, stream())
+
+
 def softmax_rows(x, rows, cols):
     _l.call("softmax_rows_f16", _p(x), _ld(x), rows, cols, stream())
 
