@@ -32,6 +32,9 @@ def cost(f):
         mm = {ops.attn_fwd: 2, ops.attn_bwd_dq: 3, ops.attn_bwd_dkv: 4}[fn]  # matmuls of Nq x Nk x D executed
         name = {ops.attn_fwd: "attention fwd", ops.attn_bwd_dq: "attention bwd dQ", ops.attn_bwd_dkv: "attention bwd dK/dV"}[fn]
         return (name, mm * 2.0 * Bn * H * Nq * Nk * D * (0.5 if causal else 1.0), 0)
+    if fn is ops.attn_bwd_small:  # (Q, K, V, dO, O, lse, dQ, dK, dV, Bn, H, N, D, scale, causal): S and dP in both roles + dQ, dK, dV
+        Bn, H, N, D = a[9:13]
+        return ("attention bwd (short sequences, one launch)", 7 * 2.0 * Bn * H * N * N * D * (0.5 if a[14] else 1.0), 0)
     if fn in (ops.groupnorm_fwd, ops.groupnorm_fwd_sums, ops.groupnorm_fwd_2l):
         Bn, HW, C = (a[7], a[8], a[9]) if fn is ops.groupnorm_fwd else (a[8], a[9], a[10])  # _sums and _2l share a layout
         return ("GroupNorm(+SiLU) fwd" + (" (stats in producer)" if fn is ops.groupnorm_fwd_sums else ""), 0, 2.0 * Bn * HW * C * 2)
