@@ -258,9 +258,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
       for (int sl = 0; sl < 8; ++sl)
 #pragma unroll
         for (int w = 0; w < 4; ++w) t[w] += sl < slots ? v[sl][w] : 0;
-      for (int sl = 8; sl < slots; ++sl)
+      for (int s0 = 8; s0 < slots; s0 += 8) {  // (more than eight slots: further batches of eight)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) t[w] += p0[(long long)sl * g.G * 4 + w];
+        for (int sl = 0; sl < 8; ++sl) {
+          const vn_u64* p = p0 + (long long)(s0 + sl < slots ? s0 + sl : 0) * g.G * 4;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v[sl][w] = p[w];
+        }
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) t[w] += s0 + sl < slots ? v[sl][w] : 0;
+      }
       const double s0 = vn_fx_decode(t[0], t[1]), s1 = vn_fx_decode(t[2], t[3]);
       if constexpr (!BWD) {
         float m, r;
