@@ -154,7 +154,7 @@ class Schedule:
         cold = None if os.environ.get("VNETI_AUTOTUNE_HOT") else torch.empty(160 * 2 ** 20, dtype=torch.float32, device=self.dev)
         if os.environ.get("VNETI_AUTOTUNE_CANDS"):
             candidates = tuple(int(x) for x in os.environ["VNETI_AUTOTUNE_CANDS"].split(","))
-        cold_reps = int(os.environ.get("VNETI_AUTOTUNE_REPS", "5"))
+        cold_reps = int(os.environ.get("VNETI_AUTOTUNE_REPS", "9"))
         cache = Schedule._tile_cache
         # optional on-disk cache of the picks (profiling runs reuse a previous run's picks so that the rocprofv3
         # per-kernel averages are those of the step, not of the autotuner's probes)
