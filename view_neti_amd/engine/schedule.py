@@ -155,6 +155,7 @@ class Schedule:
         if os.environ.get("VNETI_AUTOTUNE_CANDS"):
             candidates = tuple(int(x) for x in os.environ["VNETI_AUTOTUNE_CANDS"].split(","))
         cold_reps = int(os.environ.get("VNETI_AUTOTUNE_REPS", "9"))
+        warm_a = bool(int(os.environ.get("VNETI_AUTOTUNE_WARM_A", "1")))
         cache = Schedule._tile_cache
         # optional on-disk cache of the picks (profiling runs reuse a previous run's picks so that the rocprofv3
         # per-kernel averages are those of the step, not of the autotuner's probes)
@@ -216,11 +217,15 @@ class Schedule:
                                 e.synchronize()
                                 t = s.elapsed_time(e)
                             else:
-                                # cold timing: inside the step a GEMM's operands were evicted by its predecessors;
-                                # a fill of a buffer larger than L2 + MALL between the timed launches restores that
+                                # cold timing: inside the step a GEMM's weights (and everything older) were evicted by
+                                # its predecessors — a fill of a buffer larger than L2 + MALL between the timed launches
+                                # restores that — while its activation operand was written by the launch just before it:
+                                # a no-op in-place add re-touches it after the fill (picks move by +0.4 % on the step)
                                 ts = []
                                 for _ in range(cold_reps):
                                     cold.fill_(0)
+                                    if warm_a:  # the activation operand as its producer just left it (L2 / MALL), weights cold
+                                        args[0].add_(0)
                                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                                     s.record()
                                     ops.gemm(*args, **kw)
