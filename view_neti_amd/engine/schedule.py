@@ -225,7 +225,7 @@ class Schedule:
                                 for _ in range(cold_reps):
                                     cold.fill_(0)
                                     if warm_a:  # the activation operand as its producer just left it (L2 / MALL), weights cold
-                                        args[0].add_(0)
+                                        args[0].add_(0)  # (replaying the 2-4 preceding launches instead measured no better)
                                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                                     s.record()
                                     ops.gemm(*args, **kw)
