@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0  # fp16/bf16 dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_TBS = 8.0  # HBM3E spec peak, same guide
 TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3: "gemm_kernel<64,64,32,32>",
               4: "gemm_kernel<256,128,64,64>", 5: "gemm_kernel<256,256,64,64>", 6: "gemm_kernel<256,128,64,64,ring3>",
               7: "gemm_kernel<256,128,64,32,ring3>", 8: "gemm_kernel<256,128,64,32>", 9: "gemm_kernel<128,128,64,32>",
@@ -79,6 +80,27 @@ def build_engine(args, rank, world):
     return cfg, eng
 
 
+def gemm_cost(f):
+    """(M, N, K, batch, FLOPs, algorithmic HBM bytes, MFMA floor [s], HBM floor [s]) of one bound ops.gemm launch.
+    Bytes: every operand once — A (the plain matrix, or the NHWC image an implicit conv gathers from: NOT its 9x im2col
+    expansion), the weights, the output, plus the fused epilogue operands."""
+    kw = f.keywords
+    A, Bm = f.args[0], f.args[1]
+    M = kw.get("M") or A.shape[-2]
+    N, K = kw.get("N") or Bm.shape[-2], kw.get("K") or Bm.shape[-1]
+    batch = kw.get("batch") or 1
+    conv = kw.get("conv")
+    a_bytes = (M // (conv["Ho"] * conv["Wo"])) * conv["Hi"] * conv["Wi"] * conv["Ci"] * 2 if conv else M * K * 2 * batch
+    out = f.args[2]
+    c_cols = N * (2 if kw.get("geglu") == 2 else 1)
+    extra = sum(M * c * 2 for c, key in ((N, "resid"), (N, "out2"), (c_cols, "gate")) if kw.get(key) is not None)
+    if kw.get("geglu") == 1:
+        extra -= M * N  # out2 of the GEGLU projection is [M, N/2]
+    nbytes = a_bytes + N * K * 2 * batch + M * c_cols * out.element_size() * batch + extra
+    flops = 2.0 * M * N * K * batch
+    return M, N, K, batch, flops, nbytes, flops / (MFMA_PEAK_TFLOPS * 1e12), nbytes / (HBM_PEAK_TBS * 1e12)
+
+
 def roofline_pass(eng, reps=3):
     """Average launch duration of each GEMM tile configuration, measured with HIP events on the
     launch stream by replaying exactly the step's GEMM launches back to back."""
@@ -87,25 +109,16 @@ def roofline_pass(eng, reps=3):
     for f in eng.launches():
         if getattr(f, "func", None) is not ops.gemm:
             continue
-        kw = f.keywords
-        A, Bm = f.args[0], f.args[1]
-        M = kw.get("M") or A.shape[-2]
-        N, K = kw.get("N") or Bm.shape[-2], kw.get("K") or Bm.shape[-1]
-        batch = kw.get("batch") or 1
-        tile = kw.get("tile_hint") or ops.gemm_select_tile(M, N, batch)
-        g = groups.setdefault(tile, dict(launches=[], flops=0.0, bytes=0.0))
+        M, N, K, batch, flops, nbytes, t_mfma, t_hbm = gemm_cost(f)
+        tile = f.keywords.get("tile_hint") or ops.gemm_select_tile(M, N, batch)
+        g = groups.setdefault(tile, dict(launches=[], flops=0.0, bytes=0.0, floor_s=0.0, hbm_bound=0))
         g["launches"].append(f)
-        g["flops"] += 2.0 * M * N * K * batch
-        # algorithmic HBM bytes of the launch: every operand once — A (the plain matrix, or the NHWC image an implicit
-        # conv gathers from: NOT its 9x im2col expansion), the weights, the output, plus the fused epilogue operands
-        conv = kw.get("conv")
-        a_bytes = (M // (conv["Ho"] * conv["Wo"])) * conv["Hi"] * conv["Wi"] * conv["Ci"] * 2 if conv else M * K * 2 * batch
-        out = f.args[2]
-        c_cols = N * (2 if kw.get("geglu") == 2 else 1)
-        extra = sum(M * c * 2 for c, key in ((N, "resid"), (N, "out2"), (c_cols, "gate")) if kw.get(key) is not None)
-        if kw.get("geglu") == 1:
-            extra -= M * N  # out2 of the GEGLU projection is [M, N/2]
-        g["bytes"] += a_bytes + N * K * 2 * batch + M * c_cols * out.element_size() * batch + extra
+        g["flops"] += flops
+        g["bytes"] += nbytes
+        # the launch's TRUE bound: the slower of its MFMA time and its HBM time (the short-K linears sit below the ridge
+        # of ~310 FLOP/B and are bandwidth kernels, whatever unit executes them)
+        g["floor_s"] += max(t_mfma, t_hbm)
+        g["hbm_bound"] += 1 if t_hbm > t_mfma else 0
     out = {}
     for tile, g in groups.items():
         for f in g["launches"]:
@@ -122,7 +135,8 @@ def roofline_pass(eng, reps=3):
         n = len(g["launches"])
         out[tile] = dict(n=n, total_ms=total_ms, avg_us=total_ms * 1e3 / n, flops_per_launch=g["flops"] / n,
                          bytes_per_launch=g["bytes"] / n,
-                         tflops=g["flops"] / (total_ms * 1e-3) / 1e12)
+                         tflops=g["flops"] / (total_ms * 1e-3) / 1e12,
+                         frac_of_bound=g["floor_s"] / (total_ms * 1e-3), hbm_bound_launches=g["hbm_bound"])
     return out
 
 
@@ -138,17 +152,35 @@ def pmc_traffic(tile_name: str):
         return {"traffic": None}
     dims = re.findall(r"\d+", tile_name.split(",ring")[0])
     stages = "3" if ",ring3" in tile_name else "4" if ",ring4" in tile_name else "2"
-    # every epilogue / conv instantiation of the tile (template tail: ..., EPI, CONV) counts as the same kernel
-    pats = ["gemm_kernel<" + ", ".join(dims) + ", false, true, " + stages,
-            "gemm_kernelILi" + "ELi".join(dims) + "ELb0ELb1ELi" + stages + "E"]
+
+    def targs(name):
+        """template arguments of a kernel name, demangled (`k<128, 1, true, true>`) or mangled (`kILi128ELi1ELb1ELb1EE`)"""
+        m = re.search(r"gemm8?_kernel<([^>]*)>", name)
+        if m:
+            return [a.strip() for a in m.group(1).split(",")]
+        m = re.search(r"gemm8?_kernelI((?:L[ib]\d+E)+)E", name)
+        if m:
+            return [("true" if v == "1" else "false") if t == "b" else v for t, v in re.findall(r"L([ib])(\d+)E", m.group(1))]
+        return []
+
+    # every epilogue instantiation (EPI level) of the tile counts as the same kernel; nothing else does
     if tile_name.startswith("gemm8_kernel"):
-        bn = dims[1]
-        pats = ["gemm8_kernel<" + bn + ",", "gemm8_kernelILi" + bn + "E"]
+        # gemm8_kernel<BN, EPI, CONV, HALO>: BN is the tile WIDTH (the second number of the display name), HALO its own class
+        bn, halo = dims[2], "true" if "halo" in tile_name else "false"
+
+        def match(name):
+            a = targs(name)
+            return "gemm8_kernel" in name and len(a) >= 3 and a[0] == bn and (a[3] if len(a) > 3 else "false") == halo
+    else:
+        # gemm_kernel<BM, BN, WM, WN, F32OUT, DMA, STAGES, EPI, CONV>
+        def match(name):
+            a = targs(name)
+            return "gemm_kernel" in name and "gemm8" not in name and a[:4] == dims[:4] and len(a) >= 7 and a[6] == stages
     try:
         ks = json.load(open(files[-1]))["kernels"]
     except (OSError, ValueError, KeyError):
         return {"traffic": None}
-    hit = [e for name, e in ks.items() if any(p in name for p in pats)]
+    hit = [e for name, e in ks.items() if match(name)]
     n = sum(e.get("launches", 1) for e in hit)
     if not hit or n == 0:
         return {"traffic": None}
@@ -380,8 +412,13 @@ def main():
                          "algorithmic_bytes_per_launch": d["bytes_per_launch"],
                          "algorithmic_bytes_note": "mean over this tile's launches of A (image for implicit convs) + weights "
                                                    "+ output + fused epilogue operands, each once; compare with `traffic`",
+                         "frac_of_true_bound": d["frac_of_bound"],
+                         "frac_of_true_bound_note": "sum over this tile's launches of max(FLOP / 2.5 PF, algorithmic bytes / 8 TB/s) "
+                                                    "divided by the measured time: launches below the ridge are rated against HBM",
                          "all_gemm_tiles": {TILE_NAMES[k]: {"launches": v["n"], "ms_per_step": v["total_ms"],
-                                                            "tflops": v["tflops"]} for k, v in rf.items()}},
+                                                            "tflops": v["tflops"], "frac_of_bound": v["frac_of_bound"],
+                                                            "hbm_bound_launches": v["hbm_bound_launches"]}
+                                            for k, v in rf.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             del eng

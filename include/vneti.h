@@ -77,8 +77,8 @@ typedef struct vneti_gemm_desc {
                          convs without fused upsampling; other launches fall back to 5 / 7);
                          18: the halo-patch form of 17 for stride-1 pad-1 3x3 convolutions (conv_mode 1, or 2 = the transposed
                          gather of the input gradient) with chunk-major K (conv_korder 1) on a 16-pixel grid: a block owns 16 x 16 output pixels and keeps the 18 x 18 input
-                         patch of a 64-channel chunk in LDS for all nine taps (bit-identical to 17; no split-K; other
-                         launches fall back to 17);
+                         patch of a 64-channel chunk in LDS for all nine taps (bit-identical to 17; split-K in whole 64-channel
+                         chunks; other launches fall back to 17);
                          +100 selects the register-staged (non LDS-DMA) reference variant */
   /* split-K: f32 partials go to `workspace` (>= split_k*batch*M*N*4 bytes) and a second kernel
      reduces them and applies the epilogue.  split_k 0 = heuristic (only if a workspace is given),

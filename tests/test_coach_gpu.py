@@ -328,7 +328,7 @@ data: {{train_data_dir: data/dtu/Rectified/scan65, placeholder_object_token: <ob
        augmentation_key: 0, resolution: 64}}
 model: {{arch_mlp_hidden_dims: 64, use_nested_dropout: False, word_embedding_dim: 128, arch_view_net: 15,
         arch_view_disable_tl: False, pe_sigma_exp_key: 2, output_bypass_alpha_view: 5}}
-eval: {{validation_steps: 1000}}
+eval: {{validation_steps: 3, num_denoising_steps: 2, num_validation_images: 1, validation_seeds: [0]}}
 optim: {{max_train_steps: 4, train_batch_size: 2, gradient_accumulation_steps: 1, mixed_precision: fp16}}
 """
 
@@ -368,7 +368,12 @@ def test_coach_mode1_view_mapper_only(tmp_path, monkeypatch):
     coach.train()
     assert eng.opt_step.item() == 4 and torch.isfinite(eng.params).all()
     assert not torch.equal(v0, eng.view_params_flat()), "the view mapper must train"
+    # the stand-in object mapper is inert: no prompt reaches it, so its gradient segment is exactly zero (no BOS-row dX)
+    assert float(eng.grads[: eng.n_all_obj].abs().max()) == 0.0
     out = cfg.log.exp_dir
+    # validate.py:455: mode 1 validates with the view-token prompts and the vocabulary word (camidx -> images dict + grid)
+    val = torch.load(out / "validation-iter_3-denoisesteps_2_numseeds_1_upsample_1.pt", weights_only=False)
+    assert sorted(val) == sorted(coach.train_dataset.lookup_view_token_to_camidx.values()) and val[min(val)][0].shape == (64, 64, 3)
     assert (out / "mapper-final_view.pt").exists() and not (out / "mapper-final_object.pt").exists()
     _, view = CheckpointHandler.load_mapper(out / "mapper-final_view.pt", "view")
     assert torch.equal(flatten_mapper_state(view.mapper_state()), eng.view_params_flat().cpu())

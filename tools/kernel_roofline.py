@@ -21,10 +21,12 @@ def cost(f):
     """(class, flops, bytes) of one launch; None = not classified (closures of the backward builders etc.)"""
     fn, a, kw = getattr(f, "func", None), getattr(f, "args", ()), getattr(f, "keywords", {}) or {}
     if fn is ops.gemm:
-        A, B = a[0], a[1]
-        M = kw.get("M") or A.shape[-2]
-        N, K = kw.get("N") or B.shape[-2], kw.get("K") or B.shape[-1]
-        return ("gemm / implicit-GEMM conv", 2.0 * M * N * K * (kw.get("batch") or 1), 0)
+        # rated against its TRUE bound: below the ridge (algorithmic bytes / 8 TB/s > FLOPs / 2.5 PF) a launch is a
+        # bandwidth kernel — the short-K linears (N = K = 320 / 640 at M = 16384 / 4096 ...) — and counts by bytes
+        M, N, K, batch, flops, nbytes, t_mfma, t_hbm = bench.gemm_cost(f)
+        if t_hbm > t_mfma:
+            return ("gemm, below the ridge (short-K linears: HBM-bound)", 0, nbytes)
+        return ("gemm / implicit-GEMM conv (MFMA-bound)", flops, 0)
     if fn in (ops.attn_fwd, ops.attn_bwd_dq, ops.attn_bwd_dkv):
         i = {ops.attn_fwd: 5, ops.attn_bwd_dq: 7, ops.attn_bwd_dkv: 8}[fn]
         Bn, H, Nq, Nk, D = a[i:i + 5]

@@ -114,10 +114,8 @@ class Coach:
             **first.engine_encoder_kwargs(), **kw)
         self.engine.set_lr(self.lr_schedule.lr(0))
         self.validator = None
-        if cfg.learnable_mode == 1 and cfg.eval.validation_prompts is not None:
-            self.log("learnable_mode 1: the validation grids (which sample with an object mapper) are skipped")
         if cfg.eval.validation_prompts is not None and cfg.eval.validation_steps <= cfg.optim.max_train_steps \
-                and self.rank == 0 and cfg.learnable_mode != 1:
+                and self.rank == 0:
             from .sd_weights import load_vae_decoder_weights
             from .validate import ValidationHandler
             dec_w, _ = load_vae_decoder_weights(self.sd, str(cfg.model.pretrained_model_name_or_path), device,

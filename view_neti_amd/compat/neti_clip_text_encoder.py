@@ -107,8 +107,10 @@ class HipNeTICLIPTextModel(TextEncoderWeights):
         token / position tables (the Coach writes the placeholder rows in place, coach.py:367-395)"""
         emb = self.text_model.embeddings
         mods = list(emb.mapper_object_lookup.values()) + ([emb.mapper_view] if emb.mapper_view is not None else [])
-        maps = tuple((id(t), int(t._version)) for m in mods for t in m.mapper_state().values())
-        tabs = tuple((id(self.weights[k]), int(self.weights[k]._version))
+        # (data_ptr, _version): mapper_state() returns fresh detached aliases on every call, whose id() is arbitrary and
+        # reusable; an alias shares its base's storage pointer and version counter
+        maps = tuple((int(t.data_ptr()), int(t._version)) for m in mods for t in m.mapper_state().values())
+        tabs = tuple((int(self.weights[k].data_ptr()), int(self.weights[k]._version))
                      for k in (TextEncoderWeights.KEY, "text_model.embeddings.position_embedding.weight"))
         return maps, tabs
 

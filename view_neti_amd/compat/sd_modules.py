@@ -36,11 +36,14 @@ class _LatentDist:
 
     def __init__(self, owner: "HipAutoencoderKL"):
         self._o = owner
+        # the moments are SNAPSHOT at encode() time (34 KB .. 0.5 MB): a later vae.encode() on the same static engine
+        # must not change a distribution that was returned earlier
+        self._mom = owner.engine.moments.clone()
 
     def _moments(self):
         o = self._o
         Lc = o.cfg.latent_channels
-        m = o.engine.moments.float().view(o.B, o.h, o.w, 2 * Lc).permute(0, 3, 1, 2)
+        m = self._mom.float().view(o.B, o.h, o.w, 2 * Lc).permute(0, 3, 1, 2)
         return m[:, :Lc], m[:, Lc:].clamp(-30.0, 20.0)
 
     @property
@@ -59,7 +62,7 @@ class _LatentDist:
         Lc = o.cfg.latent_channels
         eps = torch.randn((o.B, Lc, o.h, o.w), generator=generator, device=o.dev, dtype=torch.float32)
         out = torch.empty_like(eps)
-        ops.latent_sample(o.engine.moments, eps, 1.0, out, o.B, Lc, o.h * o.w)
+        ops.latent_sample(self._mom, eps, 1.0, out, o.B, Lc, o.h * o.w)
         o.last_eps = eps  # (tests: the same draw fed to TrainStepEngine.set_noise)
         return out
 
@@ -131,6 +134,9 @@ class _UNetFn(torch.autograd.Function):
             eng.ctx_k[i].copy_(contexts[i].reshape(eng.ctx_k[i].shape))
             eng.ctx_v[i].copy_(contexts[nl + i].reshape(eng.ctx_v[i].shape))
         eng.forward()
+        # the engine holds ONE set of activations: a backward is only valid against the forward that filled them last
+        owner._forward_count = getattr(owner, "_forward_count", 0) + 1
+        ctx.forward_count = owner._forward_count
         ctx.owner = owner
         ctx.shapes = [c.shape for c in contexts]
         ctx.dtypes = [c.dtype for c in contexts]
@@ -142,6 +148,11 @@ class _UNetFn(torch.autograd.Function):
         eng = ctx.owner.engine
         if not eng.need_backward:
             raise RuntimeError("HipUNet2DConditionModel was built with need_backward=False")
+        if ctx.forward_count != ctx.owner._forward_count:
+            raise RuntimeError(
+                f"backward of UNet forward #{ctx.forward_count}, but the engine has since run forward "
+                f"#{ctx.owner._forward_count}: the static engine keeps the activations of its LAST forward only (one "
+                "forward per backward; run validation / prior-preservation forwards on a second engine)")
         nl = eng.nl
         B, Co = eng.B, eng.cfg.out_channels
         eng.dpred.copy_(grad_out.permute(0, 2, 3, 1).reshape(B * eng.H * eng.W, Co))

@@ -41,7 +41,10 @@ class ValidationHandler:
         self.cfg = cfg = coach.cfg
         eng = coach.engine
         m = cfg.model
-        first = coach.mapper_object_lookup[coach.placeholder_object_token_ids[0]]
+        # learnable_mode 1 trains no object mapper (the object is a vocabulary word, dataset.py:654-668): the engine's object
+        # side is the Coach's stand-in, which no prompt reaches (placeholder -1)
+        first = coach._standin_object if cfg.learnable_mode == 1 else \
+            coach.mapper_object_lookup[coach.placeholder_object_token_ids[0]]
         h, w = coach._image_hw()
         kw = {}
         if coach.mapper_view is not None:
@@ -87,8 +90,11 @@ class ValidationHandler:
                 make_grid(imgs, len(imgs)).save(exp / f"{stem}_upsample_{ev.dtu_upsample_key}_imgs_t2i_{i}.png")
             return
         ds = coach.train_dataset
-        tokens = (ev.eval_placeholder_object_tokens or ds.placeholder_object_tokens[:1]) if cfg.learnable_mode == 3 \
-            else ds.placeholder_object_tokens[:1]
+        if cfg.learnable_mode == 1:
+            tokens = [ds.fixed_object_token]  # validate.py:455: modes 1, 2, 4, 5 share the view-token prompts; here with the word
+        else:
+            tokens = (ev.eval_placeholder_object_tokens or ds.placeholder_object_tokens[:1]) if cfg.learnable_mode == 3 \
+                else ds.placeholder_object_tokens[:1]
         result = {}
         for obj in tokens:
             per_cam = {}

@@ -93,7 +93,14 @@ __device__ __forceinline__ float vn_gelu_erf_grad(float x) {
 // so every run — any block order, any atomic order — produces bit-identical totals with 2^-40 absolute resolution over the
 // whole float range.  One accumulated quantity = 2 words; a GroupNorm slot entry = [S1.hi, S1.lo, S2.hi, S2.lo].
 typedef unsigned long long vn_u64;
+// Non-finite input (an f16 overflow upstream): float -> integer conversion of inf / NaN / > 2^63 is undefined, so v is
+// clamped to +-2^56 first (NaN -> -2^56): the statistics are then defined garbage, and the overflow is still detected the
+// way GradScaler detects it — the inf itself survives ELEMENT-WISE through the normalisation ((inf - mean) * rstd) into
+// the loss / the gradient bucket, where grads_check_finite sets found_inf (tests/test_step_gpu.py::test_overflow_skips_step).
+// An additive sentinel cannot do better: N sentinels wrap modulo 2^64 for some N <= 64, and "every tile overflowed" is the
+// likely case.
 __device__ __forceinline__ void vn_fx_encode(float v, vn_u64& hi, vn_u64& lo) {
+  v = fminf(fmaxf(v, -7.2057594e16f), 7.2057594e16f);
   const float vh = rintf(v * 16.f);
   const long long h = (long long)vh;
   const float rem = v - vh * 0.0625f;  // exact: |rem| <= 2^-5, and 0 once |v| >= 2^19

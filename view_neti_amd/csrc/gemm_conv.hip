@@ -858,6 +858,8 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     g.pad_l = d->pad_l;
     g.ups = d->ups;
     g.ldx2 = (int)(d->ldx * 2);
+    // chunk-major K walks (Ci / 64) chunks x 9 taps x 64 channels: a ragged last chunk would read the next tap's weights
+    VN_REQUIRE(!d->conv_korder || d->Ci % 64 == 0, "conv: conv_korder=1 needs Ci=%d to be a multiple of 64", d->Ci);
     g.korder = d->conv_korder ? 1 : 0;
     long long nb = d->M / (d->Ho * d->Wo);
     a_bytes = nb * d->Hi * d->Wi * d->ldx * 2;
@@ -907,8 +909,8 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   }
   if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
   VN_REQUIRE(cfg >= 1 && cfg <= kMaxTile, "gemm: unknown tile_hint %d", d->tile_hint);
-  // the 8-phase tile: LDS-DMA only; convolutions whose gather offset is linear in the tap (no fused upsample, no
-  // stride-2 transposed gather), tap-major K order
+  // the 8-phase tiles (16 / 17): LDS-DMA only; convolutions whose gather offset is linear in the tap (no fused upsample, no
+  // stride-2 transposed gather), either K order (conv_korder 0 tap-major or 1 chunk-major: the offsets are linear in both)
   // the halo-patch form of the 256x128 8-phase tile: stride-1 pad-1 3x3 convolutions (forward or transposed gather) on a
   // 16-pixel grid, chunk-major K (split-K in whole channel chunks); anything else runs as the row-major tile
   if (cfg == 18 &&

@@ -235,7 +235,11 @@ __global__ __launch_bounds__(MT) void mapper_bwd_rows_kernel(MapperParams mp, co
   const int E = mp.E, hd = mp.hd, D = mp.D, OD = mp.OD;
   const float* sv = save + (long long)r * (E + 4 * hd + 4);
   float* rg = rowgrads + (long long)r * (OD + 4 * hd);
-  const float* dw = dword_src + (long long)dword_rows[r] * ld_src;
+  // a negative source row = this mapper call reached no prompt position (a prompt without the placeholder: mode-1 captions,
+  // negative prompts): its output was never consumed, so every gradient of the row is exactly zero
+  const int src_row = dword_rows[r];
+  const bool live = src_row >= 0;
+  const float* dw = dword_src + (long long)(live ? src_row : 0) * ld_src;
   // ---- through F.normalize * norm_scale ----
   float dot = 0.f;
   if (norm_scale > 0.f)
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(MT) void mapper_bwd_rows_kernel(MapperParams mp, co
     } else {
       g = dbypass ? dbypass[(long long)r * D + (o - D)] : 0.f;
     }
+    g = live ? g : 0.f;
     dout[o] = g;
     rg[o] = g;
   }

@@ -191,7 +191,10 @@ class TextEngine(Schedule):
         self.ids.copy_(ids)
         self.pos_obj.copy_(po)
         base = (torch.arange(nl).view(nl, 1) * B + torch.arange(B).view(1, B)) * L
-        self.rows_obj.copy_((base + po.clamp(min=0).view(1, B)).reshape(-1).to(torch.int32))
+        # rows of the residual stream whose dX the mapper backward gathers; -1 (no placeholder in the prompt) = no gradient:
+        # the mapper's output reached nothing, its bucket segment must stay frozen (vneti_mapper_bwd zeroes such rows)
+        self.rows_obj.copy_(torch.where(po.view(1, B) >= 0, base + po.view(1, B), torch.full_like(base, -1))
+                            .reshape(-1).to(torch.int32))
         if self.mv is not None:
             if placeholder_view is None or bool((placeholder_view == -1).all()):
                 self.pos_view.fill_(-1)
