@@ -374,10 +374,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt_rank = dt
+    rank_dts = [dt]
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tall = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dt], dtype=torch.float64, device="cuda"))
+        rank_dts = [float(t.item()) for t in tall]
+        dt = max(rank_dts)  # the contract's MAX over ranks
     loss = eng.loss()
 
     if rank == 0 and args.no_roofline:
@@ -399,6 +401,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "dist_backend": backend if world > 1 else None, "rccl_ranks": dist.get_world_size() if dist else 1,
                        "rank0_ms_per_step": dt_rank / args.steps * 1e3,
+                       "rank_ms_per_step_min": min(rank_dts) / args.steps * 1e3,
+                       "rank_ms_per_step_max": max(rank_dts) / args.steps * 1e3,
                        "hipgraph": not args.no_graph, "final_loss": loss,
                        "algorithmic_tflop_per_step": ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512) ** 2 / 1e3,
                        "end_to_end_mfma_frac": ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512) ** 2 / 1e3

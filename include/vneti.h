@@ -33,6 +33,11 @@ extern "C" {
 #define VNETI_ABI_VERSION 1
 
 int vneti_version(void);
+/* The 16-bit storage / MFMA operand format this build of the library computes in: 0 = IEEE half (libvneti_hip.so, the
+ * reference's `optim.mixed_precision: fp16`, training/coach.py:792-794), 1 = bfloat16 (libvneti_hip_bf16.so, its
+ * `mixed_precision: bf16` branch, training/coach.py:796-802).  Every `const void*` activation / weight operand of the
+ * entry points below (named ..._f16 for the default build) holds that format; f32 operands are unaffected. */
+int vneti_precision(void);
 /* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
 int vneti_last_error(char* buf, size_t n);
 

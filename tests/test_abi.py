@@ -7,16 +7,26 @@ import pytest
 from view_neti_amd import lib
 
 
-def test_header_symbols_exported():
-    if not os.path.exists(lib.SO_PATH):
+@pytest.mark.parametrize("precision,code", [("fp16", 0), ("bf16", 1)])
+def test_header_symbols_exported(precision, code):
+    """both builds of the library (fp16: libvneti_hip.so, bf16: libvneti_hip_bf16.so, the same sources with -DVN_BF16)"""
+    path = lib.so_path(precision)
+    if not os.path.exists(path):
         import __graft_entry__
         __graft_entry__.build()
-    so = ctypes.CDLL(lib.SO_PATH)
+    so = ctypes.CDLL(path)
     names = lib.declared_symbols()
     assert len(names) >= 15
     missing = [n for n in names if not hasattr(so, n)]
     assert not missing, f"declared in vneti.h but not exported: {missing}"
-    assert so.vneti_version() == 1
+    assert so.vneti_version() == 1 and so.vneti_precision() == code
+
+
+def test_one_precision_per_process():
+    lib.load()
+    with pytest.raises(RuntimeError):
+        lib.set_precision("bf16" if lib.precision() == "fp16" else "fp16")
+    lib.set_precision(lib.precision())  # re-stating the loaded one is fine
 
 
 def test_error_convention_no_gpu():
@@ -32,6 +42,6 @@ def test_error_convention_no_gpu():
 
 def test_signatures_cover_header():
     names = set(lib.declared_symbols())
-    covered = {"vneti_" + k for k in lib.SIGNATURES} | {"vneti_version", "vneti_last_error", "vneti_gemm_f16",
+    covered = {"vneti_" + k for k in lib.SIGNATURES} | {"vneti_version", "vneti_precision", "vneti_last_error", "vneti_gemm_f16",
                                                        "vneti_groupnorm_ws_floats"} | {"vneti_" + k for k in lib.LL_FUNCS} | {"vneti_" + k for k in lib.INT_FUNCS}
     assert names <= covered, f"no ctypes signature for {sorted(names - covered)}"

@@ -373,7 +373,9 @@ def test_coach_mode1_view_mapper_only(tmp_path, monkeypatch):
     out = cfg.log.exp_dir
     # validate.py:455: mode 1 validates with the view-token prompts and the vocabulary word (camidx -> images dict + grid)
     val = torch.load(out / "validation-iter_3-denoisesteps_2_numseeds_1_upsample_1.pt", weights_only=False)
-    assert sorted(val) == sorted(coach.train_dataset.lookup_view_token_to_camidx.values()) and val[min(val)][0].shape == (64, 64, 3)
+    ds = coach.train_dataset
+    assert sorted(val) == sorted(ds.lookup_view_token_to_camidx[t] for t in ds.placeholder_view_tokens)  # the training views
+    assert tuple(val[min(val)][0].shape) == (*coach._image_hw(), 3)
     assert (out / "mapper-final_view.pt").exists() and not (out / "mapper-final_object.pt").exists()
     _, view = CheckpointHandler.load_mapper(out / "mapper-final_view.pt", "view")
     assert torch.equal(flatten_mapper_state(view.mapper_state()), eng.view_params_flat().cpu())

@@ -83,9 +83,11 @@ def _worker_cfg4(rank, world, port, out):
     g = torch.full((total,), float(rank + 1))
     active = 37
     plan = parallel.reduce_plan(n_obj, K, active, total)
+    c0 = parallel.COLLECTIVE_CALLS
     moved = parallel.all_reduce_plan_(g, plan)
+    picks = parallel.share_from_rank0({("k", 1): (16, 1, 0)} if rank == 0 else None)  # the autotuner's broadcast path
     if rank == 0:
-        torch.save({"moved": moved, "plan": plan, "active": g[active * n_obj:(active + 1) * n_obj].clone(),
+        torch.save({"moved": moved, "plan": plan, "calls": parallel.COLLECTIVE_CALLS - c0, "picks": picks, "active": g[active * n_obj:(active + 1) * n_obj].clone(),
                     "view": g[K * n_obj:].clone(), "other": g[:n_obj].clone(), "bucket_bytes": total * 4}, out)
     dist.destroy_process_group()
 
@@ -99,6 +101,7 @@ def test_dp_config4_reduces_only_the_active_scene_and_the_view_mapper(tmp_path):
     mp.spawn(_worker_cfg4, args=(2, port, out), nprocs=2, join=True)
     r = torch.load(out)
     assert r["bucket_bytes"] == 89 * 141696 * 4 and r["moved"] == 2 * 141696 * 4
-    assert len(r["plan"]) == 2
+    assert len(r["plan"]) == 2 and r["calls"] == 1, "two slices, ONE collective (packed)"
+    assert r["picks"] == {("k", 1): (16, 1, 0)}
     assert bool((r["active"] == 3.0).all()) and bool((r["view"] == 3.0).all())  # rank 0 (1.0) + rank 1 (2.0)
     assert bool((r["other"] == 1.0).all()), "segments of other scenes must not move"

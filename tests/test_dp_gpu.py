@@ -66,12 +66,21 @@ def _worker(rank, world, port, mode3, out):
     eng.capture()
     assert eng.graph_b is not None, "world_size > 1 must split the step around the all-reduce"
     p0 = eng.params.clone()
-    losses, reduced = [], []
+    # every rank replays ONE schedule: rank 0 autotuned, the others took its picks (engine/schedule.py::autotune)
+    from view_neti_amd import ops, parallel
+    picks = [(f.keywords.get("tile_hint"), f.keywords.get("split_k"), (f.keywords.get("conv") or {}).get("korder"))
+             for f in eng.launches() if getattr(f, "func", None) is ops.gemm]
+    all_picks = [None] * world
+    dist.all_gather_object(all_picks, picks)
+    assert len(picks) > 50 and all(p == all_picks[0] for p in all_picks), "ranks pinned different GEMM tiles / split-K factors"
+    losses, reduced, calls = [], [], []
     for step in range(STEPS):
         _feed(cfg, eng, step, rank, mode3)
         # == eng.step(), spelled out so the all-reduced gradient bucket can be looked at before AdamW clears it
         eng.graph_a.replay()
+        c0 = parallel.COLLECTIVE_CALLS
         eng.all_reduce()
+        calls.append(parallel.COLLECTIVE_CALLS - c0)
         reduced.append(eng.grads.cpu().clone())
         eng.graph_b.replay()
         losses.append(eng.loss())
@@ -81,7 +90,8 @@ def _worker(rank, world, port, mode3, out):
     dist.all_gather(gathered, mine)
     if rank == 0:
         torch.save({"all": gathered, "p0": p0.cpu(), "losses": losses, "opt_step": int(eng.opt_step.item()),
-                    "reduced": reduced, "scale": float(eng.scaler[0]),
+                    "reduced": reduced, "scale": float(eng.scaler[0]), "calls": calls, "moved": eng.last_reduce_bytes,
+                    "n_obj": eng.n_obj, "n_view": eng.grads.numel() - eng.n_all_obj,
                     "seg_step": eng.seg_step.cpu().tolist(), "grad_div": float(eng.hyper[5])}, out)
     dist.barrier()
     dist.destroy_process_group()
@@ -97,6 +107,10 @@ def test_two_ranks_on_the_hip_engine_equal_grad_accumulation(tmp_path, mode3, mo
     a, b = res["all"]
     assert torch.equal(a, b), "the two ranks' parameters must be bit-identical after the all-reduced steps"
     assert res["opt_step"] == STEPS and res["grad_div"] == 2.0 and all(l == l and l > 0 for l in res["losses"])
+    # ONE collective per optimisation step (north_star), also in mode 3 where the active scene's segment and the view
+    # mapper are packed into one contiguous buffer; the payload is exactly those two segments
+    assert res["calls"] == [1] * STEPS
+    assert res["moved"] == 4 * (res["n_obj"] + (res["n_view"] if mode3 else 0))
     # ---- one process, the same two micro-batches per step through gradient accumulation ----
     monkeypatch.setenv("VNETI_NO_GN_FUSE", "1")  # same (atomics-free, deterministic) schedule as the workers
     cfg, eng = _build(1, 2, mode3)

@@ -27,7 +27,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .. import parallel
+from .. import lib, parallel
 from .. import sd_config as sc
 from ..engine.step import TrainStepEngine
 from ..engine.text import unflatten_mapper_state
@@ -60,13 +60,15 @@ class Coach:
         self._setup_logging()
         if cfg.optim.seed is not None:
             torch.manual_seed(cfg.optim.seed)
-        if cfg.optim.mixed_precision != "fp16":
+        if cfg.optim.mixed_precision not in ("fp16", "bf16"):
             # the reference default is "no" (fp32 everywhere, config.py:241); that path does not exist here and
-            # running fp16 under a config that says otherwise would be a silent change of numerics
+            # running 16-bit under a config that says otherwise would be a silent change of numerics
             raise NotImplementedError(
-                f"optim.mixed_precision='{cfg.optim.mixed_precision}': the HIP engine implements the fp16 path only "
-                "(frozen UNet/VAE in f16, f32 statistics and accumulation, device GradScaler); pass "
-                "--optim.mixed_precision fp16")
+                f"optim.mixed_precision='{cfg.optim.mixed_precision}': the HIP engine implements the two 16-bit branches of "
+                "training/coach.py:792-802 (frozen UNet/VAE in f16 or bf16, f32 statistics and accumulation; the device "
+                "GradScaler for fp16 only, as accelerate does); pass --optim.mixed_precision fp16 or bf16")
+        # _get_weight_dtype (coach.py:792-802): the process computes in ONE 16-bit format — the fp16 or the bf16 build
+        lib.set_precision(cfg.optim.mixed_precision)
         if cfg.optim.gradient_checkpointing:
             # accepted as a no-op: it trades memory for recompute without changing numerics, and the engine's saved
             # activations fit (13.5 GiB at bs=4)

@@ -19,6 +19,7 @@ from typing import Dict, Optional
 
 import torch
 
+from .. import lib
 from .. import sd_config as sc
 from ..engine.text import MapperState, TextEngine, flatten_mapper_state
 from .checkpoint_handler import TextEncoderWeights
@@ -75,7 +76,7 @@ class HipNeTICLIPTextModel(TextEncoderWeights):
             mo_mod = emb.mapper_object_lookup[obj_id]
             D, L = self.cfg.hidden_size, self.cfg.max_positions
             ts = torch.zeros(B, dtype=torch.int64, device=self.dev)
-            ck = torch.zeros((self.nl, B * L, D), dtype=torch.float16, device=self.dev)
+            ck = torch.zeros((self.nl, B * L, D), dtype=lib.act_dtype(), device=self.dev)
             cv = torch.zeros_like(ck)
             w = mo_mod.encoder.w.to(self.dev).float().contiguous()
             mo = MapperState(flatten_mapper_state(mo_mod.mapper_state()).to(self.dev), None if mo_mod.legacy else w,

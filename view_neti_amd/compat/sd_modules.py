@@ -23,7 +23,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .. import ops
+from .. import lib, ops
 from .. import sd_config as sc
 from ..engine.step import alphas_cumprod
 from ..engine.unet import UNetEngine
@@ -76,7 +76,7 @@ class HipAutoencoderKL:
         self.engine = VAEEncoderEngine(cfg, weights, batch, height, width, device)
         self.h, self.w = self.engine.h_out, self.engine.w_out
         self.config = SimpleNamespace(scaling_factor=cfg.scaling_factor, latent_channels=cfg.latent_channels)
-        self.dtype = torch.float16
+        self.dtype = lib.act_dtype()
         self.last_eps = None
 
     def to(self, *_, **__):  # coach.py:792-794 moves / casts the module; the engine already lives on the device in f16
@@ -172,7 +172,7 @@ class HipUNet2DConditionModel:
         self.engine = UNetEngine(cfg, weights, batch, height, width, ctx_len, device, need_backward)
         self.config = SimpleNamespace(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
                                       cross_attention_dim=cfg.cross_attention_dim)
-        self.dtype = torch.float16
+        self.dtype = lib.act_dtype()
 
     def to(self, *_, **__):
         return self

@@ -20,7 +20,7 @@ from typing import Dict, Optional, Union
 
 import torch
 
-from .. import ops
+from .. import lib, ops
 
 _HEAD_DIMS = (40, 64, 80, 160)
 
@@ -28,7 +28,7 @@ _HEAD_DIMS = (40, 64, 80, 160)
 def _w16(lin, transpose=False):
     w = lin.weight.detach()
     w = w.t() if transpose else w
-    return w.to(torch.float16).contiguous()
+    return w.to(lib.act_dtype()).contiguous()
 
 
 class _Packed:
@@ -59,7 +59,7 @@ def _packed(attn) -> _Packed:
 
 
 def _mm(A, W, bias=None):
-    out = torch.empty((A.shape[0], W.shape[0]), dtype=torch.float16, device=A.device)
+    out = torch.empty((A.shape[0], W.shape[0]), dtype=lib.act_dtype(), device=A.device)
     ops.gemm(A, W, out, bias=bias)
     return out
 
@@ -90,7 +90,7 @@ class _XTIAttentionFn(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         pk = ctx.pk
         B, N, Nk, C, heads, D, scale, Dk, Dv = ctx.dims
-        dout2 = dout.reshape(B * N, C).to(torch.float16).contiguous()
+        dout2 = dout.reshape(B * N, C).to(lib.act_dtype()).contiguous()
         do = _mm(dout2, pk.wo_t)
         delta = torch.empty((B * heads, N), dtype=torch.float32, device=q.device)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -123,14 +123,14 @@ class HipXTIAttenProc:
             raise NotImplementedError("attention_mask: Stable Diffusion never passes one to these modules")
         if _ehs is not None and getattr(attn, "cross_attention_norm", False):
             raise NotImplementedError("cross_attention_norm (xti_attention_processor.py:34-36) is off for every SD model")
-        if hidden_states.dtype != torch.float16 or not hidden_states.is_cuda:
+        if hidden_states.dtype != lib.act_dtype() or not hidden_states.is_cuda:
             raise TypeError("HipXTIAttenProc runs the fp16 path on the GPU (coach.py:792-794 hard-casts the UNet)")
         B, N, C = hidden_states.shape
         heads = attn.heads
         if C % heads or C // heads not in _HEAD_DIMS:
             raise NotImplementedError(f"head dim {C // heads if C % heads == 0 else C / heads} not in {_HEAD_DIMS}")
         hidden_states = hidden_states.contiguous()
-        k_src = hidden_states if _ehs is None else _ehs.to(torch.float16).contiguous()
-        v_src = k_src if _ehs_bypass is None else _ehs_bypass.to(torch.float16).contiguous()
+        k_src = hidden_states if _ehs is None else _ehs.to(lib.act_dtype()).contiguous()
+        v_src = k_src if _ehs_bypass is None else _ehs_bypass.to(lib.act_dtype()).contiguous()
         out = _XTIAttentionFn.apply(hidden_states, k_src, v_src, _packed(attn), heads)
         return attn.to_out[1](out)                                            # dropout(p=0), :55

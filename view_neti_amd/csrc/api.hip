@@ -22,6 +22,7 @@ int vneti_check_launch(const char* what) {
 }
 
 extern "C" int vneti_version(void) { return VNETI_ABI_VERSION; }
+extern "C" int vneti_precision(void) { return VN_PRECISION; }
 
 extern "C" int vneti_last_error(char* buf, size_t n) {
   size_t len = strlen(g_err);

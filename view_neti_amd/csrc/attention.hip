@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, (D <= 40 && QW == 1 ? 4 : 2)) void attn_fwd_ke
 #pragma unroll
         for (int u = 0; u < QW; ++u) {
           if constexpr (LAB & 2) asm volatile("" : "+v"(s[u][aa]) : "v"(kf));
-          else s[u][aa] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][ks], s[u][aa], 0, 0, 0);
+          else s[u][aa] = VN_MFMA_32x32x16(kf, qf[u][ks], s[u][aa], 0, 0, 0);
         }
       }
     }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, (D <= 40 && QW == 1 ? 4 : 2)) void attn_fwd_ke
 #pragma unroll
           for (int u = 0; u < QW; ++u) {
             if constexpr (LAB & 2) asm volatile("" : "+v"(o[u][db]) : "v"(vf), "v"(pf[u]));
-            else o[u][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[u][db], 0, 0, 0);
+            else o[u][db] = VN_MFMA_32x32x16(vf, pf[u], o[u][db], 0, 0, 0);
           }
         }
       }
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dq_kernel(AttnAr
         const int off = (aa * 32 + l31) * C::ROW + (ks * 2 + h2) * 16;
         half8 kf = as_half8(*reinterpret_cast<const u32x4*>(Ks + off));
         half8 vf = as_half8(*reinterpret_cast<const u32x4*>(Vs + off));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
+        s = VN_MFMA_32x32x16(kf, qf[ks], s, 0, 0, 0);
+        dp = VN_MFMA_32x32x16(vf, dof[ks], dp, 0, 0, 0);
       }
       if (need_mask) {
 #pragma unroll
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dq_kernel(AttnAr
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
           half8 tf = load_tr(Ks, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, pf, dq[db], 0, 0, 0);
+          dq[db] = VN_MFMA_32x32x16(tf, pf, dq[db], 0, 0, 0);
         }
       }
     }
@@ -668,8 +668,8 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnA
         const int off = (hq * 32 + l31) * C::ROW + (ks * 2 + h2) * 16;
         half8 qfr = as_half8(*reinterpret_cast<const u32x4*>(Qs + off));
         half8 dofr = as_half8(*reinterpret_cast<const u32x4*>(dOs + off));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dofr, vf[ks], dp, 0, 0, 0);
+        s = VN_MFMA_32x32x16(qfr, kf[ks], s, 0, 0, 0);
+        dp = VN_MFMA_32x32x16(dofr, vf[ks], dp, 0, 0, 0);
       }
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
@@ -700,8 +700,8 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnA
         for (int db = 0; db < C::DB; ++db) {
           half8 dot = load_tr(dOs, C::ROW, db * 32, hq * 32 + 16 * j + 4 * h2, lane);
           half8 qtf = load_tr(Qs, C::ROW, db * 32, hq * 32 + 16 * j + 4 * h2, lane);
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf, dk[db], 0, 0, 0);
+          dv[db] = VN_MFMA_32x32x16(dot, pf, dv[db], 0, 0, 0);
+          dk[db] = VN_MFMA_32x32x16(qtf, dsf, dk[db], 0, 0, 0);
         }
       }
     }
@@ -853,8 +853,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(AttnArgs a) {
         const int off = (aa * 32 + l31) * C::ROW + (ks * 2 + h2) * 16;
         half8 kf = as_half8(*reinterpret_cast<const u32x4*>(Ks + off));
         half8 vf = as_half8(*reinterpret_cast<const u32x4*>(Vs + off));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp, 0, 0, 0);
+        s = VN_MFMA_32x32x16(kf, qf[ks], s, 0, 0, 0);
+        dp = VN_MFMA_32x32x16(vf, dof[ks], dp, 0, 0, 0);
       }
       if (aa * 32 + 32 > N || (a.causal && aa == wave)) {
 #pragma unroll
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(AttnArgs a) {
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
           half8 tf = load_tr(Ks, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, pf, dq[db], 0, 0, 0);
+          dq[db] = VN_MFMA_32x32x16(tf, pf, dq[db], 0, 0, 0);
         }
       }
     }
@@ -927,8 +927,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(AttnArgs a) {
         const int off = (hq * 32 + l31) * C::ROW + (ks * 2 + h2) * 16;
         half8 qfr = as_half8(*reinterpret_cast<const u32x4*>(Qs + off));
         half8 dofr = as_half8(*reinterpret_cast<const u32x4*>(dOs + off));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dofr, vf[ks], dp, 0, 0, 0);
+        s = VN_MFMA_32x32x16(qfr, kf[ks], s, 0, 0, 0);
+        dp = VN_MFMA_32x32x16(dofr, vf[ks], dp, 0, 0, 0);
       }
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
@@ -959,8 +959,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(AttnArgs a) {
         for (int db = 0; db < C::DB; ++db) {
           half8 dot = load_tr(dOs, C::ROW, db * 32, hq * 32 + 16 * j + 4 * h2, lane);
           half8 qtf = load_tr(Qs, C::ROW, db * 32, hq * 32 + 16 * j + 4 * h2, lane);
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf, dk[db], 0, 0, 0);
+          dv[db] = VN_MFMA_32x32x16(dot, pf, dv[db], 0, 0, 0);
+          dk[db] = VN_MFMA_32x32x16(qtf, dsf, dk[db], 0, 0, 0);
         }
       }
     }

@@ -12,6 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SO = os.path.join(HERE, "libvneti_hip.so")
+# the same sources with -DVN_BF16 (common.h: half_t = __bf16, bf16 MFMA opcodes): the reference's mixed_precision=bf16 branch
+SO_BF16 = os.path.join(HERE, "libvneti_hip_bf16.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
          "-ffast-math" if False else "-fno-fast-math"]
@@ -34,10 +36,10 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force):
-    obj = os.path.join(HERE, "build", os.path.basename(src)[:-4] + ".o")
+def _compile(src, force, bf16=False):
+    obj = os.path.join(HERE, "build_bf16" if bf16 else "build", os.path.basename(src)[:-4] + ".o")
     if force or _stale(obj, [src] + _headers()):
-        cmd = ["hipcc", *FLAGS, "-c", src, "-o", obj]
+        cmd = ["hipcc", *FLAGS, *(["-DVN_BF16"] if bf16 else []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -47,17 +49,24 @@ def _compile(src, force):
 
 
 def build(force=False, verbose=True):
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    """both libraries (fp16: libvneti_hip.so, returned; bf16: libvneti_hip_bf16.so), all objects compiled in parallel"""
+    for d in ("build", "build_bf16"):
+        os.makedirs(os.path.join(HERE, d), exist_ok=True)
     srcs = sources()
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    if force or _stale(SO, objs):
-        cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", SO, *objs]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-        if verbose:
-            print(f"built {SO}")
+    jobs = [(s, False) for s in srcs] + [(s, True) for s in srcs]
+    # the big translation units first (gemm_conv.hip alone takes about a minute)
+    jobs.sort(key=lambda j: -os.path.getsize(j[0]))
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
+        objs = dict(zip(jobs, ex.map(lambda j: _compile(j[0], force, j[1]), jobs)))
+    for so, bf in ((SO, False), (SO_BF16, True)):
+        mine = [objs[(s, bf)] for s in srcs]
+        if force or _stale(so, mine):
+            cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", so, *mine]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+            if verbose:
+                print(f"built {so}")
     return SO
 
 

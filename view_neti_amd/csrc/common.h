@@ -5,10 +5,24 @@
 #include <stdio.h>
 #include <string.h>
 
+// The 16-bit storage / MFMA operand type of the whole library.  Default build: IEEE half (`optim.mixed_precision: fp16`,
+// training/coach.py:792-794).  -DVN_BF16 (csrc/build.py builds it as libvneti_hip_bf16.so): bfloat16 — accelerate's
+// `mixed_precision: bf16` branch of the reference (training/coach.py:796-802).  Same kernels, same f32 accumulation and
+// statistics; only the operand format (and therefore the MFMA opcode, which runs at the same rate) differs.
+#ifdef VN_BF16
+typedef __bf16 half_t;
+#define VN_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define VN_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define VN_PRECISION 1
+#else
 typedef _Float16 half_t;
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#define VN_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define VN_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define VN_PRECISION 0
+#endif
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+typedef half_t half4 __attribute__((ext_vector_type(4)));
+typedef half_t half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvInArgs a) {
       for (int jj = 0; jj < 2; ++jj) {
         const int j = c4 * 2 + jj;
         // D[row = channel][col = pixel]: the lane owns rows 4 * fq .. + 3 of row block j for pixel frow
-        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        f32x4 acc = VN_MFMA_16x16x32(wf[j], pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const half_t hv = (half_t)(acc[e] + bv[j][e]);

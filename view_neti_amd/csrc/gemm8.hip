@@ -371,7 +371,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                \
         _Pragma("unroll") for (int jb = 0; jb < NJB; ++jb) if (VN_GEMM8_LAB & 1)                               \
             asm volatile("" : "+v"(acc[H][J][i][jb]) : "v"(BF[jb][s]), "v"(af[i][s])); else acc[H][J][i][jb] = \
-            __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[jb][s], af[i][s], acc[H][J][i][jb], 0, 0, 0);           \
+            VN_MFMA_16x16x32(BF[jb][s], af[i][s], acc[H][J][i][jb], 0, 0, 0);           \
     __builtin_amdgcn_s_setprio(0);                                                                             \
   } while (0)
 #define VN_PHASE_SYNC()                    \
@@ -396,8 +396,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       if (VN_GEMM8_LAB & 1) {                                                                                  \
         asm volatile("" : "+v"(acc[H][0][i][0]), "+v"(acc[H][1][i][0]) : "v"(bf0[0][s]), "v"(bf1[0][s]), "v"(af[i][s])); \
       } else {                                                                                                 \
-      acc[H][0][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[0][s], af[i][s], acc[H][0][i][0], 0, 0, 0); \
-      acc[H][1][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[0][s], af[i][s], acc[H][1][i][0], 0, 0, 0); \
+      acc[H][0][i][0] = VN_MFMA_16x16x32(bf0[0][s], af[i][s], acc[H][0][i][0], 0, 0, 0); \
+      acc[H][1][i][0] = VN_MFMA_16x16x32(bf1[0][s], af[i][s], acc[H][1][i][0], 0, 0, 0); \
       }                                                                                                        \
     }                                                                                                          \
     __builtin_amdgcn_s_setprio(0);                                                                             \
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         asm volatile("" : "+v"(acc[cb >> 1][cb & 1][i][0]) : "v"(bfh[cb][s]), "v"(af[i][s]));                  \
       } else {                                                                                                 \
         acc[cb >> 1][cb & 1][i][0] =                                                                           \
-            __builtin_amdgcn_mfma_f32_16x16x32_f16(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0); \
+            VN_MFMA_16x16x32(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0); \
       }                                                                                                        \
     }                                                                                                          \
     if (!(VN_GEMM8_LAB & 32)) __builtin_amdgcn_s_setprio(0);                                                   \

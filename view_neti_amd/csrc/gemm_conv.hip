@@ -263,7 +263,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 #pragma unroll
       for (int j = 0; j < NI16; ++j)
         // operands swapped: D[row = n][col = m]  => each lane owns 4 consecutive n of one m
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
+        acc[i][j] = VN_MFMA_16x16x32(bf[buf][j], af[buf][i], acc[i][j], 0, 0, 0);
     if constexpr (NT == 256) __builtin_amdgcn_s_setprio(0);
   };
 

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(512) void gn_small_kernel(int HW, int C, int G, con
   const int c0 = gi * cpg;
   const int total = HW * hp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  typedef half2v half2_t;
   for (int i = threadIdx.x; i < cpg; i += NTH) {
     sga[i] = gamma[c0 + i];
     sbe[i] = beta[c0 + i];

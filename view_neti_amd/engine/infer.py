@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
-from .. import ops
+from .. import lib, ops
 from .. import sd_config as sc
 from .step import alphas_cumprod
 from .text import MapperState, TextEngine, flatten_mapper_state
@@ -91,7 +91,7 @@ class InferenceEngine:
         self.unet = UNetEngine(cfg.unet, unet_w, 2 * batch, self.h, self.w, L, device, need_backward=False)
         nl = cfg.unet.n_cross_layers
         self.t_text = torch.zeros(B, dtype=torch.int64, device=device)
-        self.ctx_k = torch.zeros((nl, B * L, D), dtype=torch.float16, device=device)
+        self.ctx_k = torch.zeros((nl, B * L, D), dtype=lib.act_dtype(), device=device)
         self.ctx_v = torch.zeros_like(self.ctx_k)
         po = params_object if params_object is not None else flatten_mapper_state(mapper_object).to(device)
         mo = MapperState(po, w_enc_object.to(device).float().contiguous() if legacy_pe_object is None else None,

@@ -13,7 +13,7 @@ from typing import Dict, List
 
 import torch
 
-from .. import ops, packing
+from .. import lib, ops, packing
 
 
 class T:
@@ -64,12 +64,14 @@ class Schedule:
             ops.set_default_gemm_workspace(torch.empty(16 * 2 ** 20, dtype=torch.float32, device=device))
 
     # ------------------------------------------------------------------ memory helpers
-    def _buf(self, shape, dtype=torch.float16, zero=False):
+    def _buf(self, shape, dtype=None, zero=False):
+        dtype = dtype or lib.act_dtype()  # the library's 16-bit format (fp16, or bf16 in the -DVN_BF16 build)
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
         self.bytes += t.numel() * t.element_size()
         return t
 
-    def _tmp(self, name, rows, cols, dtype=torch.float16):
+    def _tmp(self, name, rows, cols, dtype=None):
+        dtype = dtype or lib.act_dtype()
         """reusable scratch for backward temporaries (single stream => sequential lifetimes)."""
         key = f"{name}:{dtype}"
         n = rows * cols
@@ -80,7 +82,7 @@ class Schedule:
         return cur[:n].view(rows, cols)
 
     def _w16(self, t):
-        w = t.to(device=self.dev, dtype=torch.float16).contiguous()
+        w = t.to(device=self.dev, dtype=lib.act_dtype()).contiguous()
         self.bytes += w.numel() * 2
         return w
 
@@ -166,6 +168,12 @@ class Schedule:
             for k, v in json.load(open(cache_path)).items():
                 cache[ast.literal_eval(k)] = tuple(v)  # keys: repr() of tuples of ints / None / bools written below
         n_before = len(cache)
+        # data parallel: rank 0 measures, every rank replays ITS picks (ranks that tuned on their own pinned different
+        # tiles / split-K factors: the weak-scaling value was then the slowest rank's private schedule).  The other ranks
+        # wait here for rank 0's cache and find every problem of the (identical) schedule in it.
+        from .. import parallel
+        if parallel._dist() is not None and parallel._dist().get_rank() != 0:
+            cache.update(parallel.share_from_rank0(None))
         for lst in (self.fwd_pre, self.fwd, self.bwd):
             for idx, f in enumerate(lst):
                 if getattr(f, "func", None) is not ops.gemm or f.keywords.get("tile_hint"):
@@ -249,6 +257,8 @@ class Schedule:
                         f_cm.side = True
                     f = f_cm
                 lst[idx] = self._rebound(f, ops.gemm, kw)
+        if parallel._dist() is not None and parallel._dist().get_rank() == 0:
+            parallel.share_from_rank0(dict(cache))
         if cache_path and len(cache) != n_before:
             import json
             json.dump({repr(k): list(v) for k, v in cache.items()}, open(cache_path, "w"))

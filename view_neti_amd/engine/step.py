@@ -44,7 +44,7 @@ class TrainStepEngine:
                  mapper_view: Optional[Dict[str, torch.Tensor]] = None, w_enc_view: Optional[torch.Tensor] = None,
                  norm_scale_view: Optional[float] = None, alpha_view: float = 0.2, train_view: bool = True,
                  n_view_params: int = 12, lr: float = 1e-3, betas=(0.9, 0.999), adam_eps: float = 1e-8,
-                 weight_decay: float = 1e-2, loss_scale: float = 65536.0, growth_interval: int = 2000,
+                 weight_decay: float = 1e-2, loss_scale: Optional[float] = None, growth_interval: int = 2000,
                  seed: int = 0, world_size: int = 1, device_rng: bool = True, device: str = "cuda",
                  need_backward: bool = True, grad_accum: int = 1, overlap: bool = True,
                  unconstrained_object: bool = False, unconstrained_view: bool = False,
@@ -60,6 +60,13 @@ class TrainStepEngine:
         self.dev = device
         self.world_size = world_size
         self.device_rng = device_rng
+        if loss_scale is None:
+            # accelerate creates a GradScaler for mixed_precision fp16 only; bf16 has f32's exponent range: scale 1, never
+            # grown (the non-finite check and the skip-step logic stay, they cost one tiny kernel)
+            from .. import lib
+            loss_scale = 1.0 if lib.precision() == "bf16" else 65536.0
+            if lib.precision() == "bf16":
+                growth_interval = 2 ** 31 - 1
         self.growth_interval = growth_interval
         nlev = len(cfg.vae.block_out_channels)
         self.h, self.w = height >> (nlev - 1), width >> (nlev - 1)
@@ -232,8 +239,10 @@ class TrainStepEngine:
         same scene per step (same scene-sampler seed), so only that segment and the view mapper move."""
         if self.world_size > 1:
             from ..parallel import all_reduce_plan_, reduce_plan
-            self.last_reduce_bytes = all_reduce_plan_(
-                self.grads, reduce_plan(self.n_obj, self.n_objects, self.active_object, self.grads.numel()))
+            plan = reduce_plan(self.n_obj, self.n_objects, self.active_object, self.grads.numel())
+            if len(plan) > 1 and getattr(self, "_reduce_stage", None) is None:  # scene segment + view mapper, packed
+                self._reduce_stage = torch.empty(sum(b - a for a, b in plan), dtype=self.grads.dtype, device=self.grads.device)
+            self.last_reduce_bytes = all_reduce_plan_(self.grads, plan, getattr(self, "_reduce_stage", None))
 
     def step_eager(self):
         """one micro-step; the optimizer runs after every `grad_accum`-th micro-step."""

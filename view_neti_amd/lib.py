@@ -11,11 +11,47 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VNETI_LIB_PATH: kernel-development aid (A/B a lab build of the same ABI); the product path is the in-tree library
-SO_PATH = os.environ.get("VNETI_LIB_PATH") or os.path.join(_HERE, "csrc", "libvneti_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vneti.h")
 
+# One precision per process: "fp16" (libvneti_hip.so) or "bf16" (libvneti_hip_bf16.so, the same sources built with
+# -DVN_BF16) — the reference's optim.mixed_precision branches fp16 / bf16 (training/coach.py:792-802).  Chosen before the
+# first call into the library (set_precision, or VNETI_PRECISION in the environment); every 16-bit buffer of the engines
+# is allocated as act_dtype().
+_PRECISIONS = {"fp16": ("libvneti_hip.so", 0), "bf16": ("libvneti_hip_bf16.so", 1)}
+_precision = os.environ.get("VNETI_PRECISION", "fp16")
+if _precision not in _PRECISIONS:
+    raise RuntimeError(f"VNETI_PRECISION={_precision!r}: expected one of {sorted(_PRECISIONS)}")
+
 _lib = None
+
+
+def so_path(precision: str = None) -> str:
+    # VNETI_LIB_PATH: kernel-development aid (A/B a lab build of the same ABI); the product path is the in-tree library
+    return os.environ.get("VNETI_LIB_PATH") or os.path.join(_HERE, "csrc", _PRECISIONS[precision or _precision][0])
+
+
+SO_PATH = so_path()
+
+
+def precision() -> str:
+    return _precision
+
+
+def set_precision(p: str) -> None:
+    """select the library build; only before the first call into it (a process computes in ONE 16-bit format)"""
+    global _precision, SO_PATH
+    if p not in _PRECISIONS:
+        raise ValueError(f"precision {p!r}: expected one of {sorted(_PRECISIONS)}")
+    if _lib is not None and p != _precision:
+        raise RuntimeError(f"libvneti is already loaded in {_precision}; {p} needs its own process")
+    _precision = p
+    SO_PATH = so_path()
+
+
+def act_dtype():
+    """torch dtype of the 16-bit activations / packed weights the loaded library computes in"""
+    import torch
+    return torch.bfloat16 if _precision == "bf16" else torch.float16
 
 c_ll = C.c_longlong
 c_vp = C.c_void_p
@@ -71,10 +107,13 @@ def load():
         return _lib
     if not os.path.exists(SO_PATH):
         raise RuntimeError(
-            f"libvneti_hip.so not found at {SO_PATH}: build it with "
+            f"{os.path.basename(SO_PATH)} not found at {SO_PATH}: build it with "
             "`python view_neti_amd/csrc/build.py` (hipcc, gfx950). There is no fallback path.")
     lib = C.CDLL(SO_PATH)
     lib.vneti_version.restype = c_int
+    lib.vneti_precision.restype = c_int
+    if lib.vneti_precision() != _PRECISIONS[_precision][1]:
+        raise RuntimeError(f"{SO_PATH} computes in precision {lib.vneti_precision()}, the process asked for {_precision}")
     lib.vneti_last_error.argtypes = [C.c_char_p, C.c_size_t]
     lib.vneti_last_error.restype = c_int
     lib.vneti_groupnorm_ws_floats.restype = c_ll

@@ -17,11 +17,21 @@ def world_info():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+COLLECTIVE_CALLS = 0  # collectives issued by this process on the data path (tests assert ONE per optimisation step)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+
+
 def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     """in-place sum over ranks of the flat gradient bucket (no-op without a process group)."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    global COLLECTIVE_CALLS
+    dist = _dist()
+    if dist is not None:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        COLLECTIVE_CALLS += 1
     return flat
 
 
@@ -38,13 +48,42 @@ def reduce_plan(n_obj: int, n_objects: int, active: int, total: int):
     return plan
 
 
-def all_reduce_plan_(flat: torch.Tensor, plan) -> int:
-    """sum the planned slices over ranks in place; returns the payload bytes handed to the collective"""
-    moved = 0
-    for a, b in plan:
+def all_reduce_plan_(flat: torch.Tensor, plan, stage: torch.Tensor = None) -> int:
+    """sum the planned slices over ranks in place with ONE collective (north_star: one exchange step per optimisation
+    step); returns the payload bytes handed to it.  A single slice is reduced where it lies; several (learnable_mode 3: the
+    active scene's segment + the view mapper, which are not adjacent in the bucket) are packed into the contiguous `stage`
+    buffer (allocated on first use when not given), reduced there and copied back — two small device copies each way
+    instead of a second collective's launch + ring latency."""
+    moved = sum(b - a for a, b in plan) * flat.element_size()
+    if len(plan) == 1:
+        a, b = plan[0]
         all_reduce_sum_(flat[a:b])
-        moved += (b - a) * flat.element_size()
+        return moved
+    n = sum(b - a for a, b in plan)
+    if stage is None or stage.numel() < n:
+        stage = torch.empty(n, dtype=flat.dtype, device=flat.device)
+    off = 0
+    for a, b in plan:
+        stage[off:off + b - a].copy_(flat[a:b])
+        off += b - a
+    all_reduce_sum_(stage[:n])
+    off = 0
+    for a, b in plan:
+        flat[a:b].copy_(stage[off:off + b - a])
+        off += b - a
     return moved
+
+
+def share_from_rank0(obj):
+    """rank 0's `obj` (any picklable value) on every rank; the identity without a process group.  Control plane only (the
+    autotuner's tile picks, once per engine build): every rank must replay ONE schedule, or the weak-scaling value is the
+    slowest rank's private pick and results differ across world sizes."""
+    dist = _dist()
+    if dist is None:
+        return obj
+    box = [obj if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 def data_seed(base_seed: int, rank: int) -> int:
