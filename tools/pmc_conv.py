@@ -12,7 +12,8 @@ x = torch.randn(B * H * W, Ci, device=dev).half()
 w = (torch.randn(Co, 9 * Ci, device=dev) * 0.03).half()
 y = torch.empty(B * H * W, Co, device=dev, dtype=torch.float16)
 ws = torch.empty(16 * 2 ** 20, dtype=torch.float32, device=dev)
-conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci)
+conv = dict(mode=1, Hi=H, Wi=W, Ci=Ci, Ho=H, Wo=W, stride=1, pad_t=1, pad_l=1, ups=0, ldx=Ci,
+            korder=int(os.environ.get("KORDER", 0)))  # (timing / counters only: the random weight has no K order)
 for _ in range(int(os.environ.get("REPS", 3))):
     ops.gemm(x, w, y, M=B * H * W, conv=conv, tile_hint=hint, workspace=ws, split_k=1)
 torch.cuda.synchronize()

@@ -50,15 +50,12 @@ constexpr int GN_IMG = 5;
 
 // tools/lab/gemm8_parts.py builds variants with pieces of the main loop removed (results are garbage) to see what the loop
 // waits for: bit 0 no MFMAs, 1 no fragment reads, 2 no staging DMAs, 3 the A gather folded into a 256 KiB window (always
-// L2 hits).  0 in the product build.
+// L2 hits).  0 in the product build.  (The switches that changed the synchronisation — no stagger, no waits, one phase per
+// K-tile, no priority — were removed in round 4 with their results recorded in DESIGN.md.)
 #ifndef VN_GEMM8_LAB
 #define VN_GEMM8_LAB 0
 #endif
-#if VN_GEMM8_LAB & 16  // (lab: no waits for the stagings inside the loops — a data race, only the duration means anything)
-#define VN_WAIT_VM(n) asm volatile("" ::: "memory")
-#else
 #define VN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#endif
 #define VN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // BN = 256: the structure of the header.  BN = 128 (the N = 128 convolutions of the VAE at 512^2 / 256^2 and the N = 320 / 640
@@ -410,6 +407,16 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   } while (0)
   if constexpr (HALO) {
     constexpr int BRING = 2 * PATCH_STRIDE;   // the B tiles live behind the two patch slots
+    // Swizzle key of patch pixel column px (0..17): physical chunk = logical chunk ^ key.  A ds_read_b128 is served in lane
+    // groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32): eight lanes of one k-chunk and eight of its XOR-1 neighbour,
+    // i.e. pixels dx + {0-3, 12-15} with chunk c and dx + {4-11} with chunk c ^ 1.  The row-major tiles' key (px >> 1) & 7
+    // is conflict free only for dx = 0: taps with dx = 1, 2 (six of nine) hit two bank groups twice (rocprofv3 in round 4:
+    // SQ_LDS_BANK_CONFLICT = 25 % of SQ_LDS_IDX_ACTIVE on this kernel, 0 on the row-major 256 x 256 tile).  With x_k = key of
+    // pixels 2k, 2k + 1 the two window conditions { x0 x1 x2' x3' x4' x5' x6 x7 } and { x1 x2 x3' x4' x5' x6' x7 x8 }
+    // (x' = x ^ 1) must both be permutations of 0..7, which forces x6 = x2, x8 = x0; the table below is one solution
+    // (checked exhaustively over taps, k32 sub-steps and lane groups: tools/lab/patch_swizzle.py).  Removes a quarter of the
+    // kernel's LDS cycles; its duration did not move (the loop does not wait for LDS bandwidth).
+    auto patch_key = [](const int px) { return (int)((0x270745032ull >> (4 * (px >> 1))) & 7); };
     constexpr int PROW = 18 * 128;            // bytes per patch row (18 pixels x 64 channels)
     const int c_begin = kt_begin / 9, c_end = kt_end / 9;  // this split's channel chunks (the launcher aligns splits to chunks)
     // ---- patch staging: wave-DMA number d = 8j + wave (d < 41) covers the 64 consecutive 16-byte slots q = 64d + lane of
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       const int px = p - py * 18;
       const int iy = hty * 16 + py - 1, ix = htx * 16 + px - 1;
       const bool ok = p < 324 && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-      pa_off[j] = ok ? (uint32_t)(((hb * g.Hi + iy) * g.Wi + ix) * g.ldx2 + ((cs ^ ((px >> 1) & 7)) << 4)) : VN_OOB;
+      pa_off[j] = ok ? (uint32_t)(((hb * g.Hi + iy) * g.Wi + ix) * g.ldx2 + ((cs ^ patch_key(px)) << 4)) : VN_OOB;
     }
     const int np_wave = wave == 0 ? 6 : 5;  // patch DMAs of this wave per chunk
     auto issueP = [&](const int j, const int chunk) {  // + chunk * 128 keeps an out-of-range offset out of range (< 2 GiB)
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       // fragment reads: lane (frow = pixel column of the tile row, fq = 8-channel chunk of the k32 sub-step)
       int lb[3];
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) lb[dx] = (wr4 * 4) * PROW + (frow + dx) * 128 + ((fq ^ (((frow + dx) >> 1) & 7)) << 4);
+      for (int dx = 0; dx < 3; ++dx) lb[dx] = (wr4 * 4) * PROW + (frow + dx) * 128 + ((fq ^ patch_key(frow + dx)) << 4);
       const int rb0 = (wc2 * 64 + frow) * 128 + ((fq ^ fkey) << 4);  // (sub-step 1: ^ 64 = chunk + 4)
       half8 bfh[4][2];  // the wave's four 16-column blocks of a B tile: read in Q0, held over both phases
       if constexpr (VN_GEMM8_LAB & 2) {
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #define VN_MMA4(HALF)                                                                                          \
   do {                                                                                                         \
     VN_WAIT_LGKM0();                                                                                           \
-    if (!(VN_GEMM8_LAB & 32)) __builtin_amdgcn_s_setprio(1);                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 2 * HALF; i < 2 * HALF + 2; ++i) \
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                     \
       if (VN_GEMM8_LAB & 1) {                                                                                  \
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
             VN_MFMA_16x16x32(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0); \
       }                                                                                                        \
     }                                                                                                          \
-    if (!(VN_GEMM8_LAB & 32)) __builtin_amdgcn_s_setprio(0);                                                   \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
   } while (0)
       // ---- prologue: the whole patch of chunk 0, B tiles 0 and 1 ----
 #pragma unroll
@@ -499,13 +506,18 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       VN_STAMP(1);
-      if (wr == 1 && !(VN_GEMM8_LAB & 128)) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+      if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
       __builtin_amdgcn_sched_barrier(0);
       // K-tile t = (chunk c, tap): Q0 reads the wave's four column blocks of B(t) and two of its four tile rows at the
       // tap's offset [12 ds_read_b128], stages B(t + 2) [its buffer was last read in Q0(t - 1)] [+ one DMA of chunk c + 1's
       // patch at taps 1..6: its slot was last read in Q1 of the previous chunk's tap 8, three phases before]; Q1 reads the
       // other two tile rows [4] and waits for B(t + 1) (read in the next Q0): everything but this tile's stagings, which
       // come later in the stream.
+      // (Round 4, measured on one box against this loop, all bit-identical: eight reads per phase with column blocks 2, 3 of
+      //  B(t + 1) prefetched in Q1 and the wait moved into Q0: equal; every phase's reads issued behind the previous phase's
+      //  MFMAs — a whole interval before their use — interleaved with them: +5 %, strictly after them: +9 % slower.  The loop
+      //  is neither bound by the balance of the two load sections nor by exposed LDS latency; SQ counters: MFMA busy 40 % of
+      //  the kernel where the row-major 256 x 256 tile on a same-FLOP convolution has 59 %, L2 read latency 2.2x as long.)
       int c = c_begin, tap = 0, rbuf = 0, sbuf = 2;
       for (int t = 0; t < T; ++t) {
         const int dy = tap_dy(tap), dx = tap_dx(tap);
@@ -518,15 +530,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         issueBt(t + 2, sbuf);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (VN_GEMM8_LAB & 64) {  // (lab: one phase of 32 MFMAs per K-tile, every read up front)
-          readAh(1, ab);
-          VN_WAIT_VM(2);
-          __builtin_amdgcn_s_barrier();
-          __builtin_amdgcn_sched_barrier(0);
-          VN_MMA4(0);
-          VN_MMA4(1);
-          VN_PHASE_END();
-        } else {
         VN_MMA4(0);
         VN_PHASE_END();
         // Q1
@@ -538,7 +541,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         }
         VN_MMA4(1);
         VN_PHASE_END();
-        }
         tap += 1;
         if (tap == 9) {
           tap = 0;
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #undef VN_SYNC
   }
   VN_STAMP(2);
-  if (wr == 0 && !(HALO && (VN_GEMM8_LAB & 128))) __builtin_amdgcn_s_barrier();  // balance the stagger
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the (zero-filling) stagings past the end must have landed
   __syncthreads();                                                // before the epilogue reuses the buffers as its C tile
 #undef VN_MMA
