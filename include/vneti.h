@@ -463,6 +463,20 @@ int vneti_img_affine_nearest(const void* in, void* out, int h, int w, const int*
 /* (uint8 / 127.5 - 1) -> f32 CHW plane set (dataset.py:738-739): writes straight into the VAE's input buffer */
 int vneti_img_to_f32_chw(const void* img, float* out, int h, int w, void* stream);
 
+/* ---- data-parallel exchange: ONE all-reduce(sum) of the flat f32 mapper-gradient bucket per
+   optimisation step, on the caller's stream, straight into RCCL over xGMI (csrc/comm.hip).  Replaces the DDP all-reduce
+   accelerate performs behind `accelerator.backward(loss)` for the wrapped text encoder (training/coach.py:97-99, 211-218);
+   the mean is folded into vneti_adamw_flat's grad_div.  RCCL is resolved with dlopen on first use (a copy the process
+   already holds is reused); there is no fallback — without it these entry points fail with VNETI_EUNSUP.
+     vneti_comm_unique_id   rank 0: 128 opaque bytes to hand to every rank over any side channel (ncclGetUniqueId)
+     vneti_comm_init        every rank, collectively: -> *comm (ncclCommInitRank on the current device)
+     vneti_allreduce_flat   in place, sum over ranks, n floats; stream-ordered, no host sync
+     vneti_comm_destroy     releases the communicator (NULL is fine) */
+int vneti_comm_unique_id(void* id128);
+int vneti_comm_init(const void* id128, int rank, int world, void** comm);
+int vneti_allreduce_flat(void* comm, float* buf, long long n, void* stream);
+int vneti_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

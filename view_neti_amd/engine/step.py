@@ -59,6 +59,15 @@ class TrainStepEngine:
         self.B, self.H, self.W = batch, height, width
         self.dev = device
         self.world_size = world_size
+        if world_size > 1:
+            import os
+            import torch.distributed as dist
+            # opt-in: the exchange as a call into the library's own RCCL communicator (vneti_allreduce_flat) instead of
+            # torch.distributed.all_reduce — same collective, same ring; the default stays torch's communicator, which
+            # the driver's multi-GPU bench has exercised
+            if os.environ.get("VNETI_RCCL_DIRECT") == "1" and dist.is_initialized() and dist.get_backend() == "nccl":
+                from ..parallel import enable_direct_rccl
+                enable_direct_rccl()
         self.device_rng = device_rng
         if loss_scale is None:
             # accelerate creates a GradScaler for mixed_precision fp16 only; bf16 has f32's exponent range: scale 1, never

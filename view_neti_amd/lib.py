@@ -225,6 +225,10 @@ SIGNATURES = {
     "text_final_bwd": [c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp, c_f, c_int, c_vp, c_vp, c_vp,
                        c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "cast_f32_f16": [c_vp, c_vp, c_ll, c_vp],
+    "comm_unique_id": [c_vp],
+    "comm_init": [c_vp, c_int, c_int, C.POINTER(c_vp)],
+    "allreduce_flat": [c_vp, c_vp, c_ll, c_vp],
+    "comm_destroy": [c_vp],
     "mapper_inputs": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp],
 }
 

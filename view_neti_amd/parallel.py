@@ -25,12 +25,59 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
 
 
+class RcclComm:
+    """An RCCL communicator behind the C ABI (include/vneti.h: vneti_comm_unique_id / vneti_comm_init /
+    vneti_allreduce_flat / vneti_comm_destroy; csrc/comm.hip): the step's one exchange as a stream-ordered library call —
+    what a binder of the C ABI that does not run torch.distributed uses, and capturable in the step's hipGraph.
+    `exchange(obj)` must return rank 0's `obj` on every rank (any side channel: here torch.distributed's object broadcast
+    over the already initialised process group; a 128-byte id is all that crosses it)."""
+
+    def __init__(self, rank: int, world: int, exchange=None):
+        import ctypes as C
+        from . import lib
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            lib.call("comm_unique_id", buf)
+        uid = (exchange or share_from_rank0)(bytes(buf.raw) if rank == 0 else None)
+        self._h = C.c_void_p()
+        lib.call("comm_init", uid, rank, world, C.byref(self._h))
+        self.rank, self.world = rank, world
+
+    def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
+        from . import lib
+        assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.is_cuda
+        lib.call("allreduce_flat", self._h, flat.data_ptr(), flat.numel(), torch.cuda.current_stream().cuda_stream)
+        return flat
+
+    def close(self):
+        from . import lib
+        if self._h:
+            lib.call("comm_destroy", self._h)
+            self._h = None
+
+
+_direct: "RcclComm" = None  # set by enable_direct_rccl(): the exchange goes through vneti_allreduce_flat instead of torch
+
+
+def enable_direct_rccl():
+    """route the step's all-reduce through the library's own RCCL communicator (VNETI_RCCL_DIRECT=1 does this when a
+    TrainStepEngine with world_size > 1 is built on the nccl backend).  Needs an initialised process group for the id."""
+    global _direct
+    dist = _dist()
+    if _direct is None and dist is not None:
+        _direct = RcclComm(dist.get_rank(), dist.get_world_size())
+    return _direct
+
+
 def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     """in-place sum over ranks of the flat gradient bucket (no-op without a process group)."""
     global COLLECTIVE_CALLS
     dist = _dist()
     if dist is not None:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if _direct is not None:
+            _direct.all_reduce_sum_(flat)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         COLLECTIVE_CALLS += 1
     return flat
 
