@@ -28,6 +28,8 @@
 //     row retires them one barrier later than the other).
 //   * epilogue: the gemm_conv.hip one (C tile through LDS, bias / row-add / residual / activation / gate / GEGLU /
 //     GroupNorm sums, EPI levels), split-K partials straight from the accumulators.
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_args.h"
 
@@ -471,8 +473,51 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
           af[i][1] = as_half8(*reinterpret_cast<const u32x4*>(smem + (ab ^ 64) + i * PROW));
         }
       };
-      auto readBh = [&](const int buf) {
-        const char* b = smem + BRING + buf * BBUF;
+      // 16 MFMAs: two row blocks x four column blocks x two k32 sub-steps (accumulator [h][j][i] = column block 2h + j).
+      // PREP = scalar / address work of the NEXT K-tile, placed inside the MFMA block where SALU / VALU issue beside the
+      // matrix pipe for free (as the row-major loops do with their staging offsets).
+#define VN_MMA4(HALF, PREP)                                                                                    \
+  do {                                                                                                         \
+    VN_WAIT_LGKM0();                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    PREP;                                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 2 * HALF; i < 2 * HALF + 2; ++i) \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                     \
+      if (VN_GEMM8_LAB & 1) {                                                                                  \
+        asm volatile("" : "+v"(acc[cb >> 1][cb & 1][i][0]) : "v"(bfh[cb][s]), "v"(af[i][s]));                  \
+      } else {                                                                                                 \
+        acc[cb >> 1][cb & 1][i][0] =                                                                           \
+            VN_MFMA_16x16x32(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0);                       \
+      }                                                                                                        \
+    }                                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+  } while (0)
+      // The loop is UNROLLED OVER THE NINE TAPS of a channel chunk, so that everything a K-tile's load sections need besides
+      // the loads themselves is an immediate or a register prepared outside the tile: tap (dy, dx) -> patch offset, B ring
+      // slots (t % 3 == tap % 3 because 9 % 3 == 0), the patch piece tap - 1.  Round 4: with that arithmetic in the loop — tap
+      // decode, two select chains over registers, slot counters: ~70 instructions of issue at the head of every Q0 load
+      // section against the partner's 258 cycles of MFMAs — a barrier-to-barrier interval took ~450 cycles (stamps; SQ
+      // counters: MFMA busy 40 % of the kernel, the row-major 256 x 256 tile 59 %).  The row-major loops had shown the same
+      // effect (+21 %) with their address work in the load section; hoisting it into the MFMA block as they do does not work
+      // here — the selects compile to branches, which the scheduler cannot weave between MFMAs.
+      //   abt[k]   LDS offset of the A fragments (tile row 0, k32 sub-step 0) for the k-th K-tile of a chunk; the transposed
+      //            gather (dgrad) reads patch pixel (y + 2 - dy, x + 2 - dx) = the forward offset of tap 8 - k
+      //   bo0/bo1  source offsets of the two halves of the B tile staged next (+128 B per K-tile)
+      //   pp[j]    source offset of patch piece j of the NEXT chunk (+128 B per chunk)
+      int abt[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int tp = e_conv == 2 ? 8 - k : k, dy = tp / 3, dx = tp - 3 * dy;
+        abt[k] = (dx == 0 ? lb[0] : (dx == 1 ? lb[1] : lb[2])) + dy * PROW + (c_begin & 1) * PATCH_STRIDE;
+      }
+      uint32_t bo0 = b_base[0] + (uint32_t)(kt_begin + 2) * 128u, bo1 = b_base[2] + (uint32_t)(kt_begin + 2) * 128u;
+      uint32_t pp[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) pp[j] = pa_off[j] + (uint32_t)(c_begin + 1) * 128u;
+      const bool w0 = wave == 0;  // wave 0 stages six patch pieces per chunk, the others five
+      char* const bring = smem + BRING + wave * 1024;
+      auto readBh = [&](const int slot) {  // slot: compile-time after unrolling
+        const char* b = smem + BRING + slot * BBUF;
         if (VN_GEMM8_LAB & 2) return;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
@@ -480,22 +525,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
           bfh[cb][1] = as_half8(*reinterpret_cast<const u32x4*>(b + cb * 2048 + (rb0 ^ 64)));
         }
       };
-      // 16 MFMAs: two row blocks x four column blocks x two k32 sub-steps (accumulator [h][j][i] = column block 2h + j)
-#define VN_MMA4(HALF)                                                                                          \
-  do {                                                                                                         \
-    VN_WAIT_LGKM0();                                                                                           \
-    __builtin_amdgcn_s_setprio(1);                                                                             \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 2 * HALF; i < 2 * HALF + 2; ++i) \
-        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                     \
-      if (VN_GEMM8_LAB & 1) {                                                                                  \
-        asm volatile("" : "+v"(acc[cb >> 1][cb & 1][i][0]) : "v"(bfh[cb][s]), "v"(af[i][s]));                  \
-      } else {                                                                                                 \
-        acc[cb >> 1][cb & 1][i][0] =                                                                           \
-            VN_MFMA_16x16x32(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0); \
-      }                                                                                                        \
-    }                                                                                                          \
-    __builtin_amdgcn_s_setprio(0);                                                                             \
-  } while (0)
       // ---- prologue: the whole patch of chunk 0, B tiles 0 and 1 ----
 #pragma unroll
       for (int j = 0; j < 6; ++j)
@@ -508,46 +537,75 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       VN_STAMP(1);
       if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
       __builtin_amdgcn_sched_barrier(0);
-      // K-tile t = (chunk c, tap): Q0 reads the wave's four column blocks of B(t) and two of its four tile rows at the
-      // tap's offset [12 ds_read_b128], stages B(t + 2) [its buffer was last read in Q0(t - 1)] [+ one DMA of chunk c + 1's
-      // patch at taps 1..6: its slot was last read in Q1 of the previous chunk's tap 8, three phases before]; Q1 reads the
-      // other two tile rows [4] and waits for B(t + 1) (read in the next Q0): everything but this tile's stagings, which
-      // come later in the stream.
-      // (Round 4, measured on one box against this loop, all bit-identical: eight reads per phase with column blocks 2, 3 of
-      //  B(t + 1) prefetched in Q1 and the wait moved into Q0: equal; every phase's reads issued behind the previous phase's
-      //  MFMAs — a whole interval before their use — interleaved with them: +5 %, strictly after them: +9 % slower.  The loop
-      //  is neither bound by the balance of the two load sections nor by exposed LDS latency; SQ counters: MFMA busy 40 % of
-      //  the kernel where the row-major 256 x 256 tile on a same-FLOP convolution has 59 %, L2 read latency 2.2x as long.)
-      int c = c_begin, tap = 0, rbuf = 0, sbuf = 2;
-      for (int t = 0; t < T; ++t) {
-        const int dy = tap_dy(tap), dx = tap_dx(tap);
-        const int ab = (dx == 0 ? lb[0] : (dx == 1 ? lb[1] : lb[2])) + (c & 1) * PATCH_STRIDE + dy * PROW;
-        const bool stage_p = tap >= 1 && tap <= np_wave && c + 1 < c_end;
+      // K-tile (chunk c, tap): Q0 reads the wave's four column blocks of B(t) and two of its four tile rows at the tap's
+      // offset [12 ds_read_b128], stages B(t + 2) [its buffer was last read in Q0(t - 1)] [+ one DMA of chunk c + 1's patch
+      // at taps 1..6: its slot was last read in Q1 of the previous chunk's tap 8, three phases before]; Q1 reads the other
+      // two tile rows [4] and waits for B(t + 1) (read in the next Q0): everything but this tile's stagings, which come
+      // later in the stream.  Stagings past the end of K (the last chunk's taps 7, 8; patch pieces behind the last chunk)
+      // are issued with out-of-range offsets: they fetch nothing and keep the counted waits uniform.
+      // (Round 4, measured against this loop, all bit-identical: eight reads per phase with column blocks 2, 3 of B(t + 1)
+      //  prefetched in Q1 and the wait moved into Q0: equal; every phase's reads issued behind the previous phase's MFMAs,
+      //  interleaved with them: +5 %, strictly after them: +9 % slower.)
+      auto ktile = [&](auto tap_c, const bool last_chunk, const int pslot) {
+        constexpr int tap = decltype(tap_c)::value;
+        constexpr int rslot = tap % 3, sslot = (tap + 2) % 3;
+        const int ab = abt[tap];
         // Q0
-        readBh(rbuf);
+        readBh(rslot);
         readAh(0, ab);
-        if (stage_p) issueP(tap - 1, c + 1);
-        issueBt(t + 2, sbuf);
+        if constexpr (tap >= 1 && tap <= 6) {
+          if (tap < 6 || w0) {
+            if (!(VN_GEMM8_LAB & 4))
+              dma16(rsA, smem + pslot + ((tap - 1) * 8) * 1024 + wave * 1024, last_chunk ? VN_OOB : pp[tap - 1]);
+          }
+        }
+        {
+          const uint32_t dead = (last_chunk && tap >= 7) ? VN_OOB : 0u;
+          if (!(VN_GEMM8_LAB & 4)) {
+            dma16(rsB, bring + sslot * BBUF, bo0 | dead);
+            dma16(rsB, bring + sslot * BBUF + HB_BYTES, bo1 | dead);
+          }
+          bo0 += 128u;
+          bo1 += 128u;
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        VN_MMA4(0);
+        VN_MMA4(0, (void)0);
         VN_PHASE_END();
         // Q1
         readAh(1, ab);
-        if (stage_p) {
+        if constexpr (tap >= 1 && tap <= 5) {
           VN_SYNC(3);
+        } else if constexpr (tap == 6) {
+          if (w0) {
+            VN_SYNC(3);
+          } else {
+            VN_SYNC(2);
+          }
         } else {
           VN_SYNC(2);
         }
-        VN_MMA4(1);
+        VN_MMA4(1, (void)0);
         VN_PHASE_END();
-        tap += 1;
-        if (tap == 9) {
-          tap = 0;
-          c += 1;
-        }
-        rbuf = rbuf == 2 ? 0 : rbuf + 1;
-        sbuf = sbuf == 2 ? 0 : sbuf + 1;
+      };
+      for (int c = c_begin; c < c_end; ++c) {
+        const bool last_chunk = c + 1 >= c_end;
+        const int pslot = ((c + 1) & 1) * PATCH_STRIDE;  // where the next chunk's patch goes
+        ktile(std::integral_constant<int, 0>{}, last_chunk, pslot);
+        ktile(std::integral_constant<int, 1>{}, last_chunk, pslot);
+        ktile(std::integral_constant<int, 2>{}, last_chunk, pslot);
+        ktile(std::integral_constant<int, 3>{}, last_chunk, pslot);
+        ktile(std::integral_constant<int, 4>{}, last_chunk, pslot);
+        ktile(std::integral_constant<int, 5>{}, last_chunk, pslot);
+        ktile(std::integral_constant<int, 6>{}, last_chunk, pslot);
+        ktile(std::integral_constant<int, 7>{}, last_chunk, pslot);
+        ktile(std::integral_constant<int, 8>{}, last_chunk, pslot);
+        // the next chunk reads the other patch slot; its successor's pieces come from 64 channels further on
+        const int flip = (c & 1) ? -PATCH_STRIDE : PATCH_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) abt[k] += flip;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pp[j] += 128u;
       }
 #undef VN_MMA4
     }
