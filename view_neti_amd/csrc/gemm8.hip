@@ -756,7 +756,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     return;
   }
 
-  if (e_gn_sums) {
+  if (e_gn_sums && !(HALO && g.gn_hw == g.Ho * g.Wo)) {  // (the one-image-per-tile path of the halo tile does not use it)
     vn_u64* gacc = reinterpret_cast<vn_u64*>(smem + LDS_BYTES);
     for (int i = tid; i < GN_IMG * GN_NG * 4; i += NT) gacc[i] = 0;
   }
@@ -835,6 +835,16 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   const __amdgpu_buffer_rsrc_t rsG = vn_make_rsrc(e_gate, e_gate ? 0x7fffffffu : 0u);
   const int r_first = tid / CPR;
   constexpr int RPP = NT / CPR;  // rows per pass of the block: 16 (BN = 256) or 32 (BN = 128)
+  // A halo tile is 16 x 16 pixels of ONE image (hb): when the GroupNorm / row-add groups are whole images (they are for every
+  // launch of the step: gn_hw = rows_per_group = Ho * Wo) the image of a row need not be derived per row — the per-row float
+  // quotient, the wave vote and the conditional flush were a third of the instructions of this loop, and the time-embedding
+  // chunk is one load per thread instead of sixteen (round 4: the fused statistics had made the VAE's 512^2 convolutions
+  // 408 us where the plain epilogue takes 322).
+  const bool gn_one = HALO && gn && g.gn_hw == g.Ho * g.Wo;
+  const bool ra_one = HALO && EPI >= 1 && e_rowadd && g.rows_per_group == g.Ho * g.Wo;
+  half8 av_tile = half8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (ra_one) av_tile = as_half8(vn_buf_load16(rsRA, full_chunk ? (uint32_t)(((long long)hb * g.ld_rowadd + n) * 2) : VN_OOB));
+  if (gn_one) gn_img = hb;
   for (int it0 = 0; it0 < BM / RPP; it0 += U) {
     half8 cv[U], rv[U], av[U], gv[U], gv2[U];
 #pragma unroll
@@ -847,13 +857,14 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       cv[u] = as_half8(t);
       if (Rb) rv[u] = as_half8(vn_buf_load16(rsR, ok ? (uint32_t)(((long long)m * g.ldr + n) * 2) : VN_OOB));
       if (EPI >= 1) {
-        int grp = 0;
-        if (e_rowadd) {
-          grp = (int)((float)m * rcp_rpg);  // m / rows_per_group, m < 2^24: the float quotient is off by at most one
+        if (ra_one) {
+          av[u] = av_tile;
+        } else if (e_rowadd) {
+          int grp = (int)((float)m * rcp_rpg);  // m / rows_per_group, m < 2^24: the float quotient is off by at most one
           const int rem = m - grp * g.rows_per_group;
           grp += rem >= g.rows_per_group ? 1 : (rem < 0 ? -1 : 0);
+          av[u] = as_half8(vn_buf_load16(rsRA, ok ? (uint32_t)(((long long)grp * g.ld_rowadd + n) * 2) : VN_OOB));
         }
-        if (e_rowadd) av[u] = as_half8(vn_buf_load16(rsRA, ok ? (uint32_t)(((long long)grp * g.ld_rowadd + n) * 2) : VN_OOB));
       }
       if (EPI == 2 && e_gate) {
         const long long go = (long long)m * g.ld_gate + (e_geglu == 2 ? 2 * n : n);
@@ -866,7 +877,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       const int r = r_first + RPP * (it0 + u);
       const int m = rowmem(r);
       const bool valid = m < g.M && n < g.N;
-      if (gn) {
+      if (gn && !gn_one) {
         int img = gn_img;
         if (valid) {
           img = (int)((float)m * rcp_gnhw);
@@ -961,7 +972,38 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       }
     }
   }
-  if (gn) {
+  if (gn_one) {
+    // one image per tile: no LDS atomics — the 32 threads that share a chunk column are summed in a FIXED order (cross-lane
+    // moves inside the wave, then the eight waves' partials through a 2 KiB table), so the totals are still run-to-run
+    // identical; one fixed-point encode + four global atomics per (chunk column, group half)
+    float v4[4] = {s_lo, q_lo, s_hi, q_hi};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v4[k] += __shfl_xor(v4[k], 32);
+      v4[k] += __shfl_xor(v4[k], 16);
+    }
+    static_assert(CPR == 16 || !HALO, "the halo tile is 128 columns wide");
+    float* tab = reinterpret_cast<float*>(smem + LDS_BYTES);  // [wave][chunk column][4], inside the gacc area (never zeroed here)
+    if (lane < 16) *reinterpret_cast<f32x4*>(tab + (wave * 16 + lane) * 4) = f32x4{v4[0], v4[1], v4[2], v4[3]};
+    __syncthreads();
+    if (tid < 32) {
+      const int col = tid >> 1, half = tid & 1;
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) {
+        sv += tab[(w8 * 16 + col) * 4 + 2 * half];
+        qv += tab[(w8 * 16 + col) * 4 + 2 * half + 1];
+      }
+      const int nc = n0 + col * 8;
+      const int glo = nc / g.gn_cpg;
+      const int split = (glo + 1) * g.gn_cpg - nc;
+      if (nc < g.N && (half == 0 || split < 8)) {
+        const int slot = tile_m % g.gn_slots;
+        vn_u64* dst = reinterpret_cast<vn_u64*>(e_gn_sums) + (((long long)hb * g.gn_slots + slot) * g.gn_G + glo + half) * 4;
+        vn_fx_add2(dst, sv, qv);
+      }
+    }
+  } else if (gn) {
     gn_flush();
     __syncthreads();
     const int slot = tile_m % g.gn_slots;
