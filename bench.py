@@ -385,6 +385,9 @@ def main():
     if rank == 0 and args.no_roofline:
         print(json.dumps({"value": world * args.steps / dt, "unit": "steps/s", "note": "roofline pass skipped"}))
     elif rank == 0:
+        from view_neti_amd import lib as _lib
+        prec = _lib.precision()  # "fp16" (BASELINE.json's config) unless VNETI_PRECISION=bf16 selected the bf16 build
+        prec_short = "bf16" if prec == "bf16" else "f16"
         ms = dt / args.steps * 1e3
         value = world * args.steps / dt
         rf = roofline_pass(eng)
@@ -395,8 +398,8 @@ def main():
                        if (args.model, args.resolution, args.batch) == ("sd15", 512, 4) else
                        f"TI train steps/sec ({args.model} {args.resolution}^2 bs={args.batch} per GPU)"), "value": value, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"learnable_mode 0, {args.model} shapes, {args.resolution}x{args.resolution} fp16, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec_short, "data": "synthetic",
+            "config": {"workload": f"learnable_mode 0, {args.model} shapes, {args.resolution}x{args.resolution} {prec}, "
                                    f"bs={args.batch}/GPU, grad_accum 1, full train step (VAE+16xCLIP+UNet fwd/bwd+AdamW)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "dist_backend": backend if world > 1 else None, "rccl_ranks": dist.get_world_size() if dist else 1,

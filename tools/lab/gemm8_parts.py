@@ -12,11 +12,8 @@ VARIANTS = {0: "product", 1: "no MFMAs", 2: "no fragment reads", 4: "no staging 
             11: "staging only, A from L2", 7: "nothing (barriers, prologue, epilogue)"}
 if os.environ.get("HALO"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in (0, 1, 2, 4, 3, 6, 5, 7)}
-    VARIANTS[16] = "no waits for the stagings (vmcnt) in the loop"
-    VARIANTS[32] = "no s_setprio around the MFMA blocks"
-    VARIANTS[64] = "one phase of 32 MFMAs per K-tile (2 barriers instead of 4)"
-    VARIANTS[128] = "no stagger between the two wave groups"
-    VARIANTS[192] = "one phase per K-tile, no stagger"
+    # (round 3 also had switches that changed the synchronisation — 16 no vmcnt waits (a data race), 32 no s_setprio, 64 one
+    #  phase per K-tile, 128 no stagger; their results are in DESIGN.md section 4 and the switches were removed in round 4)
 if os.environ.get("ONLY"):
     VARIANTS = {int(k): VARIANTS.get(int(k), "?") for k in os.environ["ONLY"].split(",")}
 so = lambda m: os.path.join(ROOT, "tools", "lab", f"libvneti_g8lab_{m}.so")
