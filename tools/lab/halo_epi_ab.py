@@ -33,7 +33,9 @@ for (B, H, W, Ci, Co) in [(4, 512, 512, 128, 128), (4, 256, 256, 256, 256), (4, 
     gn = dict(gn_sums=sums, gn_hw=H * W, gn_groups=G, gn_slots=S)
     ra = dict(rowadd=radd, rows_per_group=H * W)
     res = []
-    for name, extra in (("plain", {}), ("gn", gn), ("gn+rowadd", dict(gn, **ra))):
+    sums64 = torch.zeros(B, 64, G, 4, dtype=torch.int64, device=dev)
+    gn64 = dict(gn_sums=sums64, gn_hw=H * W, gn_groups=G, gn_slots=64)
+    for name, extra in (("plain", {}), ("rowadd(EPI1)", ra), ("gn", gn), ("gn slots64", gn64), ("gn+rowadd", dict(gn, **ra))):
         f = lambda: ops.gemm(x, w, y, **kw, **extra)
         res.append(f"{name} {min(t_us(f) for _ in range(3)):7.1f}us")
     print(f"conv {B}x{H}x{W} {Ci}->{Co}: " + "  ".join(res), flush=True)
