@@ -33,6 +33,17 @@
 
 namespace {
 
+// lab build (-DVN_GEMM_STAMP, tools/lab/gemm_stamps.py): thread 0 of every block records s_memtime at the section boundaries
+// into the (otherwise unused) split-K workspace
+#ifdef VN_GEMM_STAMP
+#define VN_GSTAMP(i)                                                                                                             \
+  do {                                                                                                                           \
+    if (threadIdx.x == 0 && g.ws && g.ksplit == 1) reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define VN_GSTAMP(i)
+#endif
+
 // EPI selects how much of the fused epilogue is compiled in: 0 = bias + residual (most launches), 1 = + time-embedding
 // row-add and GroupNorm sums (the resnet convolutions, every VAE conv), 2 = + activation, gate, second output, GEGLU.
 // Every runtime-switched feature in the epilogue is paid by every launch (1-2 us x 575 launches per step, DESIGN.md
@@ -60,6 +71,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
   constexpr int GN_BYTES = (F32OUT || EPI == 0) ? 0 : GN_IMG * GN_NG * 4 * 8;  // [image][group][S1.hi S1.lo S2.hi S2.lo] 64-bit words
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + GN_BYTES];
 
+  VN_GSTAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -309,8 +321,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     issue(kt_begin, 0, true);
     if (kt_begin + 1 < kt_end) issue(kt_begin + 1, 1, false);
     if (kt_begin + 2 < kt_end) issue(kt_begin + 2, 2, false);
+    VN_GSTAMP(1);
     wait_landed(kt_end - kt_begin - 1);
     __builtin_amdgcn_s_barrier();
+    VN_GSTAMP(2);
     load_frags(0, 0, 0);
     int st = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -347,6 +361,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     }
   }
 
+  VN_GSTAMP(3);
   // ---- split-K: raw f32 partials straight to the workspace ---------------------------------
   if (g.ksplit > 1) {
     float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
@@ -407,6 +422,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     }
   }
   __syncthreads();
+  VN_GSTAMP(4);
 
   // ---- epilogue phase 2: coalesced row-major stores with fused row-add / residual ------
   if constexpr (F32OUT) {
@@ -473,6 +489,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       }
       s_lo = q_lo = s_hi = q_hi = 0.f;
     };
+    // (a plain rolled loop on purpose.  Its residual / row-add / gate loads are IT serialised round trips — +3 000 cycles on a
+    // 19 000-cycle launch of the short-K linears, tools/lab/gemm_stamps.py — but requesting them U rows at a time, as the
+    // 8-phase tiles do, needs the loop unrolled: 1 500 cycles faster on those launches, 300 slower on all the others, and
+    // 1.5 % slower on the step (a launch's code is cold; its size is a per-launch cost); a one-row-ahead request in the
+    // rolled loop gained nothing.  profiles/r04_gemm_epilogue_batch_step_ab.txt)
     for (int idx = tid; idx < BM * CPR; idx += NT) {  // BM * CPR is a multiple of NT: uniform trip count
       int r = idx / CPR, c = (idx - r * CPR) * 8;
       int m = m0 + r, n = n0 + c;
@@ -586,6 +607,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
       }
     }
   }
+#ifdef VN_GEMM_STAMP
+  VN_GSTAMP(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VN_GSTAMP(6);
+#endif
 }
 
 // split-K second pass: C = epi(alpha * sum_z ws[z]) with the same fused epilogue.
