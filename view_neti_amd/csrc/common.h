@@ -13,11 +13,13 @@
 typedef __bf16 half_t;
 #define VN_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define VN_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define VN_FDOT2(a, b, c) __builtin_amdgcn_fdot2_f32_bf16((a), (b), (c), false)  /* c + a.x*b.x + a.y*b.y, f32 */
 #define VN_PRECISION 1
 #else
 typedef _Float16 half_t;
 #define VN_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define VN_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define VN_FDOT2(a, b, c) __builtin_amdgcn_fdot2((a), (b), (c), false)  /* c + a.x*b.x + a.y*b.y, f32 */
 #define VN_PRECISION 0
 #endif
 typedef half_t half8 __attribute__((ext_vector_type(8)));

@@ -931,15 +931,21 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
           *reinterpret_cast<half4*>(e_C2 + (long long)m * g.ldc2 + (n >> 1)) = o2;
         }
         if (gn) {
+          {
+            // two channels per v_dot2 (sum: against (1, 1); sum of squares: against itself): 8 VALU per row instead of 24 —
+            // the statistics were 8-12 % of the launches that carry them.  A pair never straddles the group boundary: the
+            // split is even because the channels per group are (vneti_gemm_f16 sends odd group sizes to the generic tiles).
+            const half2v one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float x = (float)v[e];
-            if (e < gn_split) {
-              s_lo += x;
-              q_lo += x * x;
-            } else {
-              s_hi += x;
-              q_hi += x * x;
+            for (int e = 0; e < 8; e += 2) {
+              const half2v p2 = {v[e], v[e + 1]};
+              if (e < gn_split) {
+                s_lo = VN_FDOT2(p2, one2, s_lo);
+                q_lo = VN_FDOT2(p2, p2, q_lo);
+              } else {
+                s_hi = VN_FDOT2(p2, one2, s_hi);
+                q_hi = VN_FDOT2(p2, p2, q_hi);
+              }
             }
           }
         }

@@ -943,7 +943,9 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
       (d->conv_mode < 1 || d->conv_mode > 2 || d->stride != 1 || d->ups || d->pad_t != 1 || d->pad_l != 1 || d->Hi != d->Ho ||
        d->Wi != d->Wo || (d->Ho & 15) || (d->Wo & 15) || (d->Ci & 63) || !d->conv_korder || batch != 1 || f32))
     cfg = 17;
+  if (cfg == 18 && d->gn_sums && (d->gn_cpg & 1)) cfg = 17;
   if ((cfg == 16 || cfg == 17) && (!dma || (d->conv_mode && (d->ups || (d->conv_mode == 2 && d->stride == 2))) ||
+                    (d->gn_sums && (d->gn_cpg & 1)) ||  // the 8-phase tiles sum the statistics two channels at a time
                     (d->M >= (1 << 24) && (d->conv_mode || d->rowadd || d->gn_sums)))) cfg = cfg == 16 ? 5 : 7;
   if ((cfg == 5 || cfg == 16) && f32) cfg = 4;
   if (cfg == 17 && f32) cfg = 7;  // the 256x256 tiles' f32 epilogue staging would not fit in LDS
