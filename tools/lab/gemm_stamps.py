@@ -11,7 +11,7 @@ CS = os.path.join(ROOT, "view_neti_amd", "csrc")
 SO = os.path.join(ROOT, "tools", "lab", "libvneti_gstamp.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     obj = "/tmp/gemm_conv_stamp.o"
-    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DVN_GEMM_STAMP", "-c",
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DVN_GEMM_STAMP", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-c",
                            os.path.join(CS, "gemm_conv.hip"), "-o", obj])
     objs = [os.path.join(CS, "build", f) for f in os.listdir(os.path.join(CS, "build")) if f.endswith(".o") and f != "gemm_conv.o"]
     subprocess.check_call(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", SO, obj, *objs])

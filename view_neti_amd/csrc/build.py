@@ -15,8 +15,11 @@ SO = os.path.join(HERE, "libvneti_hip.so")
 # the same sources with -DVN_BF16 (common.h: half_t = __bf16, bf16 MFMA opcodes): the reference's mixed_precision=bf16 branch
 SO_BF16 = os.path.join(HERE, "libvneti_hip_bf16.so")
 ARCH = "gfx950"
+# kernarg preload: the first 14 dwords of a kernel's explicit scalar / pointer parameters arrive in SGPRs with the wave
+# instead of through an s_load round trip (the GEMM kernels list their prologue's operands that way; by-value structs
+# are unaffected)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
-         "-ffast-math" if False else "-fno-fast-math"]
+         "-ffast-math" if False else "-fno-fast-math", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _headers():

@@ -49,7 +49,27 @@ namespace {
 // Every runtime-switched feature in the epilogue is paid by every launch (1-2 us x 575 launches per step, DESIGN.md
 // section 4) even though the main loops compile to the same instructions.  CONV = false drops the implicit-im2col paths.
 template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG = 2, int EPI = 2, bool CONV = true>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
+    // the fourteen dwords the prologue needs before its first loads, as explicit parameters: gfx950 delivers those in SGPRs with
+    // the wave (kernarg preload, -mllvm -amdgpu-kernarg-preload-count=16 in csrc/build.py); a by-value struct is never
+    // preloaded and costs an s_load round trip to cold memory at the head of every launch (tools/lab/kernarg_preload_lab.hip)
+    const half_t* pA, const half_t* pB, uint32_t p_a_bytes, uint32_t p_b_bytes, int p_lda, int p_ldb, int pM, int pN, int pK,
+    int p_tiles_m, int p_tiles_n, int p_split_conv /* kt_per_split | ksplit << 16 | conv_mode << 24 */, const GemmArgs gfull) {
+  GemmArgs g = gfull;  // (scalarised: only the fields a path uses are ever loaded)
+  g.A = pA;
+  g.B = pB;
+  g.a_bytes = p_a_bytes;
+  g.b_bytes = p_b_bytes;
+  g.lda = p_lda;
+  g.ldb = p_ldb;
+  g.M = pM;
+  g.N = pN;
+  g.K = pK;
+  g.tiles_m = p_tiles_m;
+  g.tiles_n = p_tiles_n;
+  g.kt_per_split = p_split_conv & 0xffff;
+  g.ksplit = (p_split_conv >> 16) & 0xff;
+  g.conv_mode = p_split_conv >> 24;
   static_assert(NSTG == 2 || ((NSTG == 3 || NSTG == 4) && DMA), "the LDS rings are LDS-DMA only");
   const half_t* const e_gate = EPI == 2 ? g.gate_src : nullptr;
   half_t* const e_C2 = EPI == 2 ? g.C2 : nullptr;
@@ -716,7 +736,9 @@ inline int epilogue_level(const GemmArgs& g) {
 template <int BM, int BN, int WM, int WN, bool F32OUT, bool DMA, int NSTG>
 void launch_variant(const GemmArgs& g, dim3 grid, hipStream_t st) {
   const dim3 block((BM / WM) * (BN / WN) * 64);
-#define VN_GO(E, C) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, F32OUT, DMA, NSTG, E, C>), grid, block, 0, st, g)
+#define VN_GO(E, C)                                                                                                        \
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, F32OUT, DMA, NSTG, E, C>), grid, block, 0, st, g.A, g.B, g.a_bytes, g.b_bytes, \
+                     (int)g.lda, (int)g.ldb, g.M, g.N, g.K, g.tiles_m, g.tiles_n, g.kt_per_split | (g.ksplit << 16) | (g.conv_mode << 24), g)
   if constexpr (F32OUT) {  // f32 outputs (split-K partials aside: the CLIP residual stream) know bias / act / residual only
     if (g.conv_mode) { if (g.act) VN_GO(2, true); else VN_GO(0, true); }
     else { if (g.act) VN_GO(2, false); else VN_GO(0, false); }
@@ -967,6 +989,7 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   g.ksplit = ks;
   g.kt_per_split = cdiv(nk, ks);
   g.ksplit = cdiv(nk, g.kt_per_split);  // drop empty trailing splits
+  VN_REQUIRE(g.ksplit <= 255 && g.kt_per_split <= 0xffff, "gemm: split_k=%d / K=%d out of range", g.ksplit, d->K);
   g.ws = (float*)d->workspace;
 
 #define LAUNCH(BM, BN, WM, WN) \
