@@ -136,6 +136,28 @@ def test_gemm_split_k(split, f32, hint):
     check(f"gemm split_k={split} f32={f32}", out, ref, 2e-3)
 
 
+@pytest.mark.parametrize("hint", [3, 9, 13, 16, 17])
+def test_gemm_epilogue_adds_round_like_f32(hint):
+    """the fused row-add and residual are 16-bit adds (packed v_pk_add_f16 in the fp16 build): bit for bit
+    half(float(half(float(c) + float(rowadd))) + float(resid)) of the plain launch's output c — including operands many
+    binades apart and on rounding ties."""
+    ops = _ops()
+    M, N, K = 256, 320, 128
+    A = rnd(M, K, seed=61).to(DEV)
+    B = rnd(N, K, scale=1.0 / math.sqrt(K), seed=62).to(DEV)
+    g = torch.Generator().manual_seed(63)
+    # residual / row-add magnitudes spread over 2^-14 .. 2^6 so that every alignment case of the adder occurs
+    res = (torch.randn(M, N, generator=g) * torch.exp2(torch.randint(-14, 7, (M, N), generator=g).float())).to(torch.float16).to(DEV)
+    radd = (torch.randn(M // 64, N, generator=g) * torch.exp2(torch.randint(-10, 3, (M // 64, N), generator=g).float())).to(torch.float16).to(DEV)
+    plain = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    fused = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(A, B, plain, tile_hint=hint, split_k=1)
+    ops.gemm(A, B, fused, resid=res, rowadd=radd, rows_per_group=64, tile_hint=hint, split_k=1)
+    torch.cuda.synchronize()
+    want = ((plain.float() + radd.float().repeat_interleave(64, 0)).to(torch.float16).float() + res.float()).to(torch.float16)
+    assert torch.equal(fused, want)
+
+
 @pytest.mark.parametrize("hint", [3, 16, 17])
 @pytest.mark.parametrize("act", [1, 2, 3])
 @pytest.mark.parametrize("split", [1, 3])

@@ -26,6 +26,20 @@ typedef half_t half8 __attribute__((ext_vector_type(8)));
 typedef half_t half4 __attribute__((ext_vector_type(4)));
 typedef half_t half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// a + b rounded to the 16-bit storage format, eight channels at a time (the residual / row-add operands of the GEMM
+// epilogues).  fp16: four v_pk_add_f16 instead of 8 x (cvt, cvt, add, cvt) — bit-identical to rounding the f32 sum: the f32
+// sum of two halfs is exact up to 12 binades apart and beyond that lies on the same side of every f16 rounding boundary
+// (checked on 10^8 random and structured pairs).  bf16 has no packed add on gfx950: through f32 as before.
+__device__ __forceinline__ half8 vn_add8(const half8 a, const half8 b) {
+#ifdef VN_BF16
+  half8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (half_t)((float)a[e] + (float)b[e]);
+  return r;
+#else
+  return a + b;
+#endif
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

@@ -893,12 +893,10 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       half8 v = cv[u];
       if (full_chunk) {
         if (EPI >= 1 && e_rowadd) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)av[u][e]);
+          v = vn_add8(v, av[u]);
         }
         if (Rb) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[u][e]);
+          v = vn_add8(v, rv[u]);
         }
         if (e_geglu == 2) {
           // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]

@@ -533,13 +533,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
       if (n + 8 <= g.N) {
         if (radd) {
           half8 t = *reinterpret_cast<const half8*>(radd);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)t[e]);
+          v = vn_add8(v, t);
         }
         if (Rb) {
           half8 rr = *reinterpret_cast<const half8*>(Rb + (long long)m * g.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+          v = vn_add8(v, rr);
         }
         if (e_geglu == 2) {
           // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]
