@@ -299,6 +299,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
     if constexpr (NT == 256) __builtin_amdgcn_s_setprio(0);
   };
 
+  // the bias of this lane's 4 * NI16 columns in one batch of buffer loads (out-of-range columns and a null bias read as
+  // zeros), requested BEFORE the K loop: it is cold like everything a launch touches first, and asked for in the epilogue
+  // it was a ~1 000-cycle wait on every tile (tools/lab/gemm_stamps.py: accumulators -> LDS 1 700 cycles)
+  // (the register-staged 16-wave reference variant has no registers to spare: it asks in the epilogue, as before)
+  constexpr bool BIAS_EARLY = DMA || NT < 1024;
+  f32x4 bv[NI16];
+  auto load_bias = [&]() {
+    const __amdgpu_buffer_rsrc_t rsBias = vn_make_rsrc(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
+#pragma unroll
+    for (int j = 0; j < NI16; ++j)
+      bv[j] = __builtin_bit_cast(f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + wn0 + j * 16 + 4 * fq) * 4u));
+  };
+  if constexpr (BIAS_EARLY) load_bias();
+
   if constexpr (NSTG == 3) {
     // 3-stage ring with cross-barrier fragment prefetch: the barrier that publishes stage s+1 sits before the
     // LAST MFMA group of step s, so the first fragments of step s+1 are fetched under it and the step boundary
@@ -411,15 +425,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
   }
   // ---- epilogue phase 1: acc -> (alpha, bias, act) -> LDS tile Cs[BM][CS_LD] ---------
   // (the trailing __syncthreads of the K loop guarantees nobody still reads the stages)
-  // the bias of this lane's 4 * NI16 columns in one batch of buffer loads (out-of-range columns and a null bias read as
-  // zeros): written as per-element conditional loads the compiler serialised eight load -> wait round trips per tile
-  f32x4 bv[NI16];
-  {
-    const __amdgpu_buffer_rsrc_t rsBias = vn_make_rsrc(g.bias, g.bias ? (uint32_t)g.N * 4u : 0u);
-#pragma unroll
-    for (int j = 0; j < NI16; ++j)
-      bv[j] = __builtin_bit_cast(f32x4, vn_buf_load16(rsBias, (uint32_t)(n0 + wn0 + j * 16 + 4 * fq) * 4u));
-  }
+  if constexpr (!BIAS_EARLY) load_bias();
 #pragma unroll
   for (int i = 0; i < MI16; ++i) {
 #pragma unroll
