@@ -346,6 +346,8 @@ int vneti_mse_loss_grad(const void* pred, long long ldp, const float* target, vo
  * phases (bit mask) lets one optimizer step span several buckets: VNETI_OPT_CHECK = unscale-time
  * inf/nan check of this bucket (sets found_inf), VNETI_OPT_APPLY = the update (skipped when
  * found_inf), VNETI_OPT_FINISH = GradScaler.update() + step advance.  One bucket: pass all three.
+ * growth_interval <= 0 = static loss scale (bf16: accelerate builds no GradScaler, training/coach.py:796-802):
+ * a non-finite step is skipped but the scale is neither halved nor grown.
  * Several: CHECK every bucket, then APPLY every bucket, FINISH on the last call. */
 #define VNETI_OPT_CHECK 1
 #define VNETI_OPT_APPLY 2

@@ -176,3 +176,113 @@ def test_two_ranks_on_the_hip_engine_equal_grad_accumulation(tmp_path, mode3, mo
         # torch.optim.AdamW semantics (DESIGN D10): a mapper joins the update set when first trained and is stepped on
         # every iteration afterwards — scene 0 from step 1, scene 2 from step 2, scene 1 never
         assert res["seg_step"] == [3, 0, 2] and eng.seg_step.cpu().tolist() == [3, 0, 2]
+
+
+def _coach_worker(rank, world, port, root, out_dir):
+    """two ranks of the reference-shaped Coach with validation ENABLED (the default): rank 0 alone builds the validator's
+    inference engines, whose autotuner must not issue collectives the other rank never joins"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import datetime
+
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
+    from view_neti_amd import parallel
+    from view_neti_amd.compat import config as C
+    from view_neti_amd.compat.coach import Coach
+    cfg = C.parse(C.RunConfig, [
+        "--data.train_data_dir", root, "--data.placeholder_object_token", "<toy>", "--data.resolution", "64",
+        "--data.dataloader_num_workers", "0", "--model.word_embedding_dim", "128", "--model.arch_view_net", "15",
+        "--model.arch_view_disable_tl", "False", "--model.arch_mlp_hidden_dims", "64", "--model.use_nested_dropout",
+        "False", "--optim.max_train_steps", "4", "--optim.train_batch_size", "2",
+        "--optim.gradient_accumulation_steps", "1", "--optim.mixed_precision", "fp16", "--log.save_steps", "4",
+        "--eval.validation_steps", "2", "--eval.num_denoising_steps", "2", "--eval.num_validation_images", "1",
+        "--eval.validation_seeds", "[0]", "--log.exp_dir", out_dir, "--log.exp_name", "dp"])
+    cfg.log.exp_dir = cfg.log.exp_dir / cfg.log.exp_name
+    cfg.log.logging_dir = cfg.log.exp_dir / cfg.log.logging_dir
+    torch.manual_seed(cfg.seed)
+    coach = Coach(cfg)
+    assert (coach.validator is not None) == (rank == 0)
+    c0 = parallel.COLLECTIVE_CALLS
+    coach.train()
+    torch.cuda.synchronize()
+    assert parallel.COLLECTIVE_CALLS - c0 == 4, "one gradient all-reduce per optimisation step, nothing else on the data path"
+    mine = coach.engine.params.cpu()
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert torch.equal(both[0], both[1]), "ranks diverged: a collective was mis-paired"
+    assert int(coach.engine.opt_step.item()) == 4 and abs(float(coach.engine.hyper[0]) - 1e-3 * 2 * 2) < 1e-9
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_coach_with_rank0_only_validator(tmp_path):
+    import numpy as np
+    from PIL import Image
+    root = tmp_path / "toys"
+    root.mkdir()
+    rng = np.random.RandomState(0)
+    for i in range(4):
+        Image.fromarray(rng.randint(0, 255, (90, 120, 3), dtype=np.uint8)).save(root / f"{i}.png")
+    port = 29950 + (os.getpid() % 40)
+    mp.spawn(_coach_worker, args=(2, port, str(root), str(tmp_path / "out")), nprocs=2, join=True)
+    out = tmp_path / "out" / "dp"
+    assert (out / "mapper-final_object.pt").exists()
+    assert (out / "validation-iter_2-denoisesteps_2_upsample_1_imgs_t2i_0.png").exists()
+
+
+def test_world2_step_is_the_world1_graph_plus_one_collective_node():
+    """north_star's exchange on the RCCL path: with a stream-ordered library communicator the data-parallel step is ONE
+    hipGraph — the one-GPU launch list, one collective node, the same fused AdamW — not graph A / host all-reduce / graph B.
+    A test box has one GPU, so the communicator is a real world-size-1 RCCL communicator (sum over ranks = identity)
+    handed to an engine that otherwise believes world_size = 2 (grad_div 2)."""
+    from view_neti_amd import ops, parallel
+    comm = parallel.RcclComm(0, 1, exchange=lambda b: b)
+    torch.manual_seed(0)
+    cfg, e1 = _build(1, 1, False)
+    torch.manual_seed(0)
+    _, e2 = _build_x(comm)
+    sig = lambda eng: [(getattr(f, "func", f).__name__, tuple(sorted((k, v) for k, v in getattr(f, "keywords", {}).items()
+                                                                   if isinstance(v, (int, float, bool, type(None))))))
+                       for f in eng.launches()]
+    assert sig(e1) == sig(e2), "the N > 1 step must replay the N = 1 launch list"
+    for eng in (e1, e2):
+        _feed(cfg, eng, 0, 0, False)
+        eng.capture()
+    assert e1.graph_b is None and e2.graph_b is None and e2.exchange_in_graph, "world 2 on RCCL: one graph"
+    assert float(e2.hyper[5]) == 2.0
+    # replay: exactly one collective per step; identical arithmetic to the eager world-2 step (same launches, same order)
+    c0 = parallel.COLLECTIVE_CALLS
+    for step in range(2):
+        _feed(cfg, e2, step, 0, False)
+        assert e2.step() is True
+    torch.cuda.synchronize()
+    assert parallel.COLLECTIVE_CALLS - c0 == 2
+    p_graph = e2.params.clone()
+    torch.manual_seed(0)
+    e3 = _build_x(comm)[1]
+    for step in range(2):
+        _feed(cfg, e3, step, 0, False)
+        assert e3.step_eager() is True
+    torch.cuda.synchronize()
+    assert torch.equal(p_graph, e3.params), "captured exchange differs from the eager one"
+    assert not torch.equal(p_graph, e1.params)
+    comm.close()
+
+
+def _build_x(comm):
+    """_build(world 2) with an injected communicator"""
+    from view_neti_amd.engine import step as step_mod
+    orig = step_mod.TrainStepEngine.__init__
+
+    def patched(self, *a, **kw):
+        kw.setdefault("exchange", comm)
+        return orig(self, *a, **kw)
+
+    step_mod.TrainStepEngine.__init__ = patched
+    try:
+        return _build(2, 1, False)
+    finally:
+        step_mod.TrainStepEngine.__init__ = orig

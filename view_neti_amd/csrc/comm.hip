@@ -38,6 +38,12 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::once_flag g_once;
+char g_load_err[256] = "symbols missing";  // why load_rccl() failed: dlerror() read ONCE, right after the failing call
+
+void keep_dlerror(const char* what) {
+  const char* e = dlerror();  // clears the state: a second call would return NULL
+  snprintf(g_load_err, sizeof g_load_err, "%s: %s", what, e ? e : "no dlerror text");
+}
 
 void load_rccl() {
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -45,19 +51,24 @@ void load_rccl() {
     g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     if (g_rccl.handle) break;
   }
-  for (int i = 0; !g_rccl.handle && i < 3; ++i) g_rccl.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  for (int i = 0; !g_rccl.handle && i < 3; ++i) {
+    g_rccl.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl.handle) keep_dlerror(names[i]);
+  }
   if (!g_rccl.handle) return;
   g_rccl.get_uid = (fn_get_uid)dlsym(g_rccl.handle, "ncclGetUniqueId");
   g_rccl.init_rank = (fn_init_rank)dlsym(g_rccl.handle, "ncclCommInitRank");
   g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.handle, "ncclAllReduce");
   g_rccl.destroy = (fn_destroy)dlsym(g_rccl.handle, "ncclCommDestroy");
   g_rccl.errstr = (fn_errstr)dlsym(g_rccl.handle, "ncclGetErrorString");
+  if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.allreduce || !g_rccl.destroy)
+    snprintf(g_load_err, sizeof g_load_err, "ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy not all exported");
 }
 
 int need_rccl() {
   std::call_once(g_once, load_rccl);
   if (!g_rccl.handle || !g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.allreduce || !g_rccl.destroy) {
-    vneti_set_error("RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    vneti_set_error("RCCL (librccl.so.1) could not be loaded: %s", g_load_err);
     return VNETI_EUNSUP;
   }
   return VNETI_OK;

@@ -426,10 +426,14 @@ __global__ __launch_bounds__(256) void grads_check_finite_segments_kernel(const 
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) scaler[2] = 1.f;
 }
-// GradScaler.update(): backoff 0.5 on inf, growth x2 every `interval` clean steps; advance step
+// GradScaler.update(): backoff 0.5 on inf, growth x2 every `interval` clean steps; advance step.
+// growth_interval <= 0: a STATIC scale (the bf16 branch: accelerate creates no GradScaler there) — a non-finite step is
+// still skipped, but the scale neither backs off nor grows
 __global__ void scaler_update_kernel(float* scaler, int* step, int growth_interval) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (scaler[2] != 0.f) {
+  if (growth_interval <= 0) {
+    if (scaler[2] == 0.f) step[0] += 1;
+  } else if (scaler[2] != 0.f) {
     scaler[0] *= 0.5f;
     scaler[1] = 0.f;
   } else {

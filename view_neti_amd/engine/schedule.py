@@ -170,9 +170,13 @@ class Schedule:
         n_before = len(cache)
         # data parallel: rank 0 measures, every rank replays ITS picks (ranks that tuned on their own pinned different
         # tiles / split-K factors: the weak-scaling value was then the slowest rank's private schedule).  The other ranks
-        # wait here for rank 0's cache and find every problem of the (identical) schedule in it.
+        # wait here for rank 0's cache and find every problem of the (identical) schedule in it.  This is a COLLECTIVE, so
+        # it happens only inside `parallel.shared_picks()` — which TrainStepEngine.__init__, run by every rank, opens —
+        # and never for an engine that one rank builds on its own (rank 0's validation / inference engines).
         from .. import parallel
-        if parallel._dist() is not None and parallel._dist().get_rank() != 0:
+        share = parallel.sharing_picks() and parallel._dist() is not None
+        rank0 = (not share) or parallel._dist().get_rank() == 0
+        if share and not rank0:
             cache.update(parallel.share_from_rank0(None))
         for lst in (self.fwd_pre, self.fwd, self.bwd):
             for idx, f in enumerate(lst):
@@ -257,11 +261,14 @@ class Schedule:
                         f_cm.side = True
                     f = f_cm
                 lst[idx] = self._rebound(f, ops.gemm, kw)
-        if parallel._dist() is not None and parallel._dist().get_rank() == 0:
+        if share and rank0:
             parallel.share_from_rank0(dict(cache))
-        if cache_path and len(cache) != n_before:
-            import json
-            json.dump({repr(k): list(v) for k, v in cache.items()}, open(cache_path, "w"))
+        if cache_path and len(cache) != n_before and parallel.world_info()[0] == 0:
+            import json  # rank 0 only, and atomically: a concurrent or torn write would poison the next run's load
+            tmp = f"{cache_path}.{os.getpid()}.tmp"
+            with open(tmp, "w") as fh:
+                json.dump({repr(k): list(v) for k, v in cache.items()}, fh)
+            os.replace(tmp, cache_path)
 
     def bind_workspace(self):
         """pin this schedule's own split-K / q-split scratch into every launch that may use one."""

@@ -50,7 +50,7 @@ class TrainStepEngine:
                  unconstrained_object: bool = False, unconstrained_view: bool = False,
                  nested_dropout_prob: float = 0.0, hidden_object: int = 64,
                  legacy_pe_object: Optional[torch.Tensor] = None, enc_dim_object: int = 64,
-                 output_bypass_object: bool = True, output_bypass_view: bool = True):
+                 output_bypass_object: bool = True, output_bypass_view: bool = True, exchange=None):
         """mapper_object: one mapper state_dict, or a list of them (learnable_mode 3: one object mapper per
         scene, `mapper_object_lookup`, training/coach.py:505-552) — `set_batch(object_index=k)` picks the one
         the batch trains."""
@@ -59,23 +59,31 @@ class TrainStepEngine:
         self.B, self.H, self.W = batch, height, width
         self.dev = device
         self.world_size = world_size
-        if world_size > 1:
+        # the exchange step.  On the nccl (= RCCL) backend it is a call into the library's own communicator
+        # (vneti_allreduce_flat, csrc/comm.hip): stream-ordered and capturable, so the data-parallel step is the SAME single
+        # hipGraph as the one-GPU step plus one collective node (capture()).  VNETI_RCCL_DIRECT=0, the gloo backend (CPU
+        # tests, two ranks on one GPU) and any failure to build the communicator fall back to torch.distributed.all_reduce
+        # issued from the host between two graphs.  `exchange` may also be handed in (tests: a world-size-1 communicator).
+        self.exchange = exchange
+        if world_size > 1 and exchange is None:
             import os
             import torch.distributed as dist
-            # opt-in: the exchange as a call into the library's own RCCL communicator (vneti_allreduce_flat) instead of
-            # torch.distributed.all_reduce — same collective, same ring; the default stays torch's communicator, which
-            # the driver's multi-GPU bench has exercised
-            if os.environ.get("VNETI_RCCL_DIRECT") == "1" and dist.is_initialized() and dist.get_backend() == "nccl":
+            if os.environ.get("VNETI_RCCL_DIRECT", "1") != "0" and dist.is_initialized() and dist.get_backend() == "nccl":
                 from ..parallel import enable_direct_rccl
-                enable_direct_rccl()
+                try:
+                    self.exchange = enable_direct_rccl()
+                except RuntimeError as err:  # loud, not fatal: torch's communicator does the same collective
+                    import warnings
+                    warnings.warn(f"library RCCL communicator unavailable ({err}); using torch.distributed.all_reduce")
         self.device_rng = device_rng
         if loss_scale is None:
-            # accelerate creates a GradScaler for mixed_precision fp16 only; bf16 has f32's exponent range: scale 1, never
-            # grown (the non-finite check and the skip-step logic stay, they cost one tiny kernel)
+            # accelerate creates a GradScaler for mixed_precision fp16 only; bf16 has f32's exponent range: a STATIC scale of 1
+            # (growth_interval 0: never halved, never grown — the non-finite check and the skip-step logic stay, they
+            # cost one tiny kernel)
             from .. import lib
             loss_scale = 1.0 if lib.precision() == "bf16" else 65536.0
             if lib.precision() == "bf16":
-                growth_interval = 2 ** 31 - 1
+                growth_interval = 0
         self.growth_interval = growth_interval
         nlev = len(cfg.vae.block_out_channels)
         self.h, self.w = height >> (nlev - 1), width >> (nlev - 1)
@@ -135,12 +143,15 @@ class TrainStepEngine:
         self.opt_step = torch.zeros(1, dtype=torch.int32, device=device)
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
         self.ac = alphas_cumprod(cfg.ddpm).to(device)
-        # ---- engines ----
-        self.unet = UNetEngine(cfg.unet, unet_w, batch, self.h, self.w, cfg.clip.max_positions, device, need_backward)
-        self.vae = VAEEncoderEngine(cfg.vae, vae_w, batch, height, width, device)
-        self.text = TextEngine(cfg.clip, clip_w, cfg.unet.n_cross_layers, batch, self.unet.timesteps, self.unet.ctx_k,
-                               self.unet.ctx_v, self.unet.dctx_k, self.unet.dctx_v, mo, self.grads[:n_all_obj], mv,
-                               gv, n_view_params, train_view, device, need_backward, rng_state=self.rng_state)
+        # ---- engines ----  (every rank builds these three in this order: the one place where the autotuner's picks are
+        # shared by a broadcast — rank-0-only engines such as the validator's stay outside, parallel.shared_picks)
+        from ..parallel import shared_picks
+        with shared_picks():
+            self.unet = UNetEngine(cfg.unet, unet_w, batch, self.h, self.w, cfg.clip.max_positions, device, need_backward)
+            self.vae = VAEEncoderEngine(cfg.vae, vae_w, batch, height, width, device)
+            self.text = TextEngine(cfg.clip, clip_w, cfg.unet.n_cross_layers, batch, self.unet.timesteps, self.unet.ctx_k,
+                                   self.unet.ctx_v, self.unet.dctx_k, self.unet.dctx_v, mo, self.grads[:n_all_obj], mv,
+                                   gv, n_view_params, train_view, device, need_backward, rng_state=self.rng_state)
         self.timesteps = self.unet.timesteps
         self.pixel_values = self.vae.x_in
         shape = (batch, Lc, self.h, self.w)
@@ -152,6 +163,7 @@ class TrainStepEngine:
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
         self.graph_a = self.graph_b = self.graph_acc = None
+        self.exchange_in_graph = False
         self.micro = 0
         self.n_loss = batch * Lc * self.h * self.w
 
@@ -251,7 +263,13 @@ class TrainStepEngine:
             plan = reduce_plan(self.n_obj, self.n_objects, self.active_object, self.grads.numel())
             if len(plan) > 1 and getattr(self, "_reduce_stage", None) is None:  # scene segment + view mapper, packed
                 self._reduce_stage = torch.empty(sum(b - a for a, b in plan), dtype=self.grads.dtype, device=self.grads.device)
-            self.last_reduce_bytes = all_reduce_plan_(self.grads, plan, getattr(self, "_reduce_stage", None))
+            self.last_reduce_bytes = all_reduce_plan_(self.grads, plan, getattr(self, "_reduce_stage", None),
+                                                      comm=self.exchange)
+
+    def _exchange_capturable(self) -> bool:
+        """the all-reduce may sit INSIDE a graph: a stream-ordered library communicator, and a plan that does not depend on
+        host state (several object mappers pack the active scene's segment, chosen per step on the host)"""
+        return self.world_size > 1 and self.exchange is not None and self.n_objects == 1
 
     def step_eager(self):
         """one micro-step; the optimizer runs after every `grad_accum`-th micro-step."""
@@ -266,8 +284,22 @@ class TrainStepEngine:
 
     # ------------------------------------------------------------------ hipGraph capture
     def capture(self):
-        """Capture the step into hipGraphs: [forward+backward] and [optimizer], with the RCCL
-        all-reduce of the flat gradient bucket between them (single graph when world_size == 1)."""
+        """Capture the step into ONE hipGraph: forward + backward, (world > 1 on RCCL: the all-reduce of the flat gradient
+        bucket as one collective node,) fused AdamW — the launch list of N GPUs is the one-GPU list plus that node.
+        Fallbacks keep the older shape [forward+backward] -> host-issued all-reduce -> [optimizer]: the gloo backend,
+        several object mappers (host-dependent exchange plan), and a communicator that refuses capture."""
+        try:
+            self._capture(self._exchange_capturable())
+        except RuntimeError as err:
+            if not self._exchange_capturable():
+                raise
+            import warnings
+            warnings.warn(f"capturing the RCCL all-reduce failed ({err}); the exchange runs between two graphs")
+            torch.cuda.synchronize()
+            self.graph_a = self.graph_b = self.graph_acc = None
+            self._capture(False)
+
+    def _capture(self, exchange_in_graph: bool):
         # the warm-up launches below are real steps: snapshot the trainable / RNG state and put it back
         saved = (self.params, self.exp_avg, self.exp_avg_sq, self.opt_step, self.scaler, self.rng_state, self.seg_step)
         state = [t.clone() for t in saved]
@@ -277,11 +309,13 @@ class TrainStepEngine:
             for _ in range(self.grad_accum):
                 self.step_eager()  # warm-up on the side stream (also primes RCCL)
             torch.cuda.synchronize()
-            fused_opt = self.world_size == 1 and self.grad_accum == 1
+            fused_opt = (self.world_size == 1 or exchange_in_graph) and self.grad_accum == 1
+            self.exchange_in_graph = exchange_in_graph
             self.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a, stream=s):
                 self.forward_backward(accumulate=False)
                 if fused_opt:
+                    self.all_reduce()  # no-op at world 1; one captured collective node otherwise
                     self.optimizer_step()
             if self.grad_accum > 1:
                 self.graph_acc = torch.cuda.CUDAGraph()
@@ -290,6 +324,8 @@ class TrainStepEngine:
             if not fused_opt:
                 self.graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_b, stream=s):
+                    if exchange_in_graph:
+                        self.all_reduce()
                     self.optimizer_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -307,8 +343,12 @@ class TrainStepEngine:
             return False
         self.micro = 0
         if self.graph_b is not None:
-            self.all_reduce()
+            if not self.exchange_in_graph:
+                self.all_reduce()
             self.graph_b.replay()
+        if self.exchange_in_graph:
+            from .. import parallel
+            parallel.COLLECTIVE_CALLS += 1  # the replayed collective node
         return True
 
     def loss(self) -> float:

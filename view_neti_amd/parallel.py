@@ -60,21 +60,49 @@ _direct: "RcclComm" = None  # set by enable_direct_rccl(): the exchange goes thr
 
 
 def enable_direct_rccl():
-    """route the step's all-reduce through the library's own RCCL communicator (VNETI_RCCL_DIRECT=1 does this when a
-    TrainStepEngine with world_size > 1 is built on the nccl backend).  Needs an initialised process group for the id."""
+    """route the step's all-reduce through the library's own RCCL communicator (the default on the nccl backend when a
+    TrainStepEngine with world_size > 1 is built; VNETI_RCCL_DIRECT=0 keeps torch's).  Needs an initialised process group
+    for the id.  The communicator belongs to ONE (rank, world): a process group re-initialised with another shape gets a
+    new one, and it is destroyed at interpreter exit (before torch tears the device context down)."""
     global _direct
     dist = _dist()
+    if _direct is not None and (dist is None or (_direct.rank, _direct.world) != (dist.get_rank(), dist.get_world_size())):
+        disable_direct_rccl()
     if _direct is None and dist is not None:
         _direct = RcclComm(dist.get_rank(), dist.get_world_size())
+        global _atexit_set
+        if not _atexit_set:
+            import atexit
+            atexit.register(disable_direct_rccl)
+            _atexit_set = True
     return _direct
 
 
-def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
-    """in-place sum over ranks of the flat gradient bucket (no-op without a process group)."""
+_atexit_set = False
+
+
+def disable_direct_rccl():
+    """destroy the library communicator (no-op when none exists); the exchange falls back to torch.distributed"""
+    global _direct
+    if _direct is not None:
+        try:
+            _direct.close()
+        finally:
+            _direct = None
+
+
+def all_reduce_sum_(flat: torch.Tensor, comm=None) -> torch.Tensor:
+    """in-place sum over ranks of the flat gradient bucket (no-op without a process group).  `comm`: an explicit
+    communicator object (RcclComm) — the call is then stream-ordered and capturable."""
     global COLLECTIVE_CALLS
+    if comm is not None:
+        comm.all_reduce_sum_(flat)
+        if not torch.cuda.is_current_stream_capturing():  # a captured node is counted per replay (TrainStepEngine.step)
+            COLLECTIVE_CALLS += 1
+        return flat
     dist = _dist()
     if dist is not None:
-        if _direct is not None:
+        if _direct is not None and (_direct.rank, _direct.world) == (dist.get_rank(), dist.get_world_size()):
             _direct.all_reduce_sum_(flat)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -95,7 +123,7 @@ def reduce_plan(n_obj: int, n_objects: int, active: int, total: int):
     return plan
 
 
-def all_reduce_plan_(flat: torch.Tensor, plan, stage: torch.Tensor = None) -> int:
+def all_reduce_plan_(flat: torch.Tensor, plan, stage: torch.Tensor = None, comm=None) -> int:
     """sum the planned slices over ranks in place with ONE collective (north_star: one exchange step per optimisation
     step); returns the payload bytes handed to it.  A single slice is reduced where it lies; several (learnable_mode 3: the
     active scene's segment + the view mapper, which are not adjacent in the bucket) are packed into the contiguous `stage`
@@ -104,7 +132,7 @@ def all_reduce_plan_(flat: torch.Tensor, plan, stage: torch.Tensor = None) -> in
     moved = sum(b - a for a, b in plan) * flat.element_size()
     if len(plan) == 1:
         a, b = plan[0]
-        all_reduce_sum_(flat[a:b])
+        all_reduce_sum_(flat[a:b], comm)
         return moved
     n = sum(b - a for a, b in plan)
     if stage is None or stage.numel() < n:
@@ -113,12 +141,36 @@ def all_reduce_plan_(flat: torch.Tensor, plan, stage: torch.Tensor = None) -> in
     for a, b in plan:
         stage[off:off + b - a].copy_(flat[a:b])
         off += b - a
-    all_reduce_sum_(stage[:n])
+    all_reduce_sum_(stage[:n], comm)
     off = 0
     for a, b in plan:
         flat[a:b].copy_(stage[off:off + b - a])
         off += b - a
     return moved
+
+
+_share_picks = 0  # depth of shared_picks() contexts
+
+
+class shared_picks:
+    """`with shared_picks():` — engines built inside share rank 0's autotuner picks through a broadcast.  Only code that
+    EVERY rank runs in the same order may open it (TrainStepEngine.__init__); an engine a single rank builds on its own
+    (rank 0's ValidationHandler -> InferenceEngine, training/coach.py:119-125 analogue) must stay outside, or its broadcasts
+    would pair with the other ranks' gradient all-reduce."""
+
+    def __enter__(self):
+        global _share_picks
+        _share_picks += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _share_picks
+        _share_picks -= 1
+        return False
+
+
+def sharing_picks() -> bool:
+    return _share_picks > 0
 
 
 def share_from_rank0(obj):
