@@ -43,7 +43,7 @@ TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3
               10: "gemm_kernel<128,128,64,32,ring3>", 11: "gemm_kernel<128,64,64,32,ring3>", 12: "gemm_kernel<64,64,32,32,ring3>",
               13: "gemm_kernel<128,128,64,32,ring4>", 14: "gemm_kernel<128,64,64,32,ring4>", 15: "gemm_kernel<64,64,32,32,ring4>",
               16: "gemm8_kernel<256,256,8-phase>", 17: "gemm8_kernel<256,128,8-phase>",
-              18: "gemm8_kernel<256,128,8-phase,halo>"}
+              18: "gemm8_kernel<256,128,8-phase,halo>", 19: "lin_kernel<64 rows x whole K resident, barrier-free column sweep>"}
 # algorithmic FLOPs per sample at 512^2, SD-1.5: VAE 1116.7 + CLIP 16x13.3 + UNet fwd 803.3
 # + UNet dgrad 929.4 + CLIP dgrad 216 GF
 ALGO_GFLOP_PER_SAMPLE_512 = 3278.0
@@ -148,7 +148,7 @@ def pmc_traffic(tile_name: str):
     import glob
     import re
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.json")))
-    if not files:
+    if not files or tile_name.startswith("lin_kernel"):
         return {"traffic": None}
     dims = re.findall(r"\d+", tile_name.split(",ring")[0])
     stages = "3" if ",ring3" in tile_name else "4" if ",ring4" in tile_name else "2"
@@ -299,6 +299,30 @@ def cpu_baseline(args):
                       f"sched affinity {aff} cpus, os.cpu_count()={os.cpu_count()}, cpu='{model}'"}
 
 
+def driver_timed_extras(cache_path):
+    """Two numbers the headline does not carry, measured AFTER the timed region so that the driver's own run records them
+    (VERDICT r4 item 5b): the end-to-end `Coach.train` rate at the headline size (dataloader-free device input pipeline,
+    set_batch, graph replay, host bookkeeping: tools/bench_coach.py, training/coach.py:154-264) and BASELINE config 5's
+    seconds per image (SD-2.1 768^2, DDIM-50, CFG: tools/bench_infer.py, sd_pipeline_call.py:73-98).  Each runs as a bounded
+    subprocess on the now idle GPU and reuses this run's autotuner picks; a failure is recorded, never fatal."""
+    import subprocess
+    env = dict(os.environ, VNETI_ALLOW_SYNTHETIC_WEIGHTS="1")
+    if cache_path:
+        env["VNETI_AUTOTUNE_CACHE"] = cache_path
+    out = {}
+    for key, cmd, field in (
+            ("coach_steps_per_s", [os.path.join(ROOT, "tools", "bench_coach.py"), "--steps", "60", "--variants", "device"], "steps_per_s"),
+            ("infer_s_per_image_cfg5", [os.path.join(ROOT, "tools", "bench_infer.py"), "--steps", "50", "--reps", "1"], "s_per_image")):
+        try:
+            r = subprocess.run([sys.executable, *cmd], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            out[key] = json.loads(line)[field]
+        except Exception as err:  # noqa: BLE001 (reported in the JSON line)
+            out[key] = None
+            out[key + "_error"] = f"{type(err).__name__}: {str(err)[:200]}"
+    return out
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks of one node, one per GPU,
     under torch.distributed.run (rendezvous on 127.0.0.1, a free port); rank 0's JSON line passes straight through."""
@@ -330,6 +354,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-tile GEMM replay (counter-collection runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip config.coach_steps_per_s / config.infer_s_per_image_cfg5")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
@@ -356,6 +381,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # this run's autotuner picks, kept for the extras' subprocesses (same problems, no second tuning pass)
+    tune_cache = None
+    if world == 1 and "VNETI_AUTOTUNE_CACHE" not in os.environ:
+        import tempfile
+        tune_cache = os.path.join(tempfile.gettempdir(), f"vneti_bench_picks_{os.getpid()}.json")
+        os.environ["VNETI_AUTOTUNE_CACHE"] = tune_cache
     cfg, eng = build_engine(args, rank, world)
     if not args.no_graph:
         eng.capture()
@@ -427,9 +458,13 @@ def main():
                                                             "hbm_bound_launches": v["hbm_bound_launches"]}
                                             for k, v in rf.items()}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        headline = (args.model, args.resolution, args.batch) == ("sd15", 512, 4)
+        if world == 1 and (not args.no_cpu_baseline or (headline and not args.no_extras)):
             del eng
             torch.cuda.empty_cache()
+        if world == 1 and headline and not args.no_extras and not args.no_cpu_baseline:
+            out["config"].update(driver_timed_extras(tune_cache or os.environ.get("VNETI_AUTOTUNE_CACHE")))
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_bounded(args)
         print(json.dumps(out))
     if dist is not None:

@@ -207,7 +207,8 @@ def _coach_worker(rank, world, port, root, out_dir):
     c0 = parallel.COLLECTIVE_CALLS
     coach.train()
     torch.cuda.synchronize()
-    assert parallel.COLLECTIVE_CALLS - c0 == 4, "one gradient all-reduce per optimisation step, nothing else on the data path"
+    # 4 optimisation steps + the warm-up step inside capture() (a real, all-reduced step whose state is rolled back)
+    assert parallel.COLLECTIVE_CALLS - c0 == 5, "one gradient all-reduce per optimisation step, nothing else on the data path"
     mine = coach.engine.params.cpu()
     both = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(both, mine)

@@ -116,41 +116,66 @@ def test_pipeline_matches_oracle(cfg_name, kind, steps):
     assert ex < 2e-2 and ei < 1e-2
 
 
-@pytest.mark.timeout(1200)
+@pytest.mark.timeout(2400)
 def test_config5_full_size_sampler_step_and_decode():
-    """BASELINE config 5 at its real size (SD-2.1 shapes, 768x768, DDIM, CFG, object + pretrained-style view mapper):
-    two captured sampler steps + the VAE decoder run, shapes are right and everything stays finite; the captured step
-    equals the eager one."""
+    """BASELINE config 5 at its real size (SD-2.1 shapes, 768x768, DDIM, CFG, object + pretrained-style view mapper)
+    AGAINST THE ORACLE: two sampler steps (each one CFG-batched UNet forward at the 96x96 latent: N = 9216, d = 64
+    self-attention) and the 768^2 VAE decode, compared with oracle/sd_ref.py's restatement of sd_pipeline_call
+    (sd_pipeline_call.py:73-98) on f16-rounded weights; the captured sampler step equals the eager one bit for bit."""
+    from oracle import sd_ref as R
     from view_neti_amd import sd_config as sc, synth
     from view_neti_amd.engine.infer import InferenceEngine
     from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
     cfg = sc.sd21()
-    B, H, W = 1, 768, 768
+    B, H, W, steps, gs, kind = 1, 768, 768, 2, 7.5, "ddim"
     D = cfg.clip.hidden_size
     dev = "cuda"
     uw, dw, cw = (synth.unet_weights(cfg.unet, device=dev), synth.vae_decoder_weights(cfg.vae, device=dev),
                   synth.clip_weights(cfg.clip, device=dev))
     torch.manual_seed(0)
-    sdo, sdv = init_mapper_state(64, 64, D), init_mapper_state(64, 64, D)
+    gen = torch.Generator().manual_seed(9)
+    mk = lambda: {k: v + 0.05 * torch.randn(v.shape, generator=gen) for k, v in init_mapper_state(64, 64, D).items()}
+    sdo, sdv = mk(), mk()
     norm = float(cw["text_model.embeddings.token_embedding.weight"][:1000].float().norm(dim=1).mean())
-    eng = InferenceEngine(cfg, uw, dw, cw, B, H, W, sdo, fourier_frequencies([0.03, 2.0], 64, 0), norm, 5.0,
-                          mapper_view=sdv, w_enc_view=fourier_frequencies([0.03, 2.0] + [0.5] * 12, 64, 0),
+    w_enc, w_enc_v = fourier_frequencies([0.03, 2.0], 64, 0), fourier_frequencies([0.03, 2.0] + [0.5] * 12, 64, 0)
+    eng = InferenceEngine(cfg, uw, dw, cw, B, H, W, sdo, w_enc, norm, 5.0, mapper_view=sdv, w_enc_view=w_enc_v,
                           norm_scale_view=norm, alpha_view=5.0)
+    # the oracle's copies: f16-rounded matrices as fp32 on the host (what the engine's packed f16 weights hold)
+    r16 = lambda d: {k: ((v.half().float() if v.dim() >= 2 and "embedding" not in k and not k.startswith("post_quant")
+                          else v.float()).cpu()) for k, v in d.items()}
+    uwr, dwr, cwr = r16(uw), r16(dw), r16(cw)
     del uw, dw, cw
     ph, phv = cfg.clip.vocab_size - 3, cfg.clip.vocab_size - 4
     ids = synth.input_ids(B, ph, cfg.clip.vocab_size, view_placeholder_id=phv)
     neg = synth.input_ids(1, ph, cfg.clip.vocab_size)
     neg[neg == ph] = 7
+    vparams = synth.gaussian((B, 12), 9).clamp(-1, 1)
     eng.set_negative_prompt(neg)
-    eng.set_prompt(ids, torch.full((B,), ph), torch.full((B,), phv), synth.gaussian((B, 12), 9).clamp(-1, 1))
+    eng.set_prompt(ids, torch.full((B,), ph), torch.full((B,), phv), vparams)
     lat = synth.gaussian((B, 4, H // 8, W // 8), 17)
-    img = eng.generate(lat, 2, 7.5, "ddim").clone()
+    img = eng.generate(lat, steps, gs, kind).clone()
     x_graph = eng.x.clone()
     assert img.shape == (B, H, W, 3) and bool(torch.isfinite(img).all()) and bool(torch.isfinite(x_graph).all())
     assert 0.0 <= float(img.min()) and float(img.max()) <= 1.0 and float(img.std()) > 0
     assert eng.unet.pred.shape[0] == 2 * B * (H // 8) * (W // 8)  # CFG-batched: unconditional + conditional halves
-    eng.generate(lat, 2, 7.5, "ddim", use_graph=False)
-    e = _rel(eng.x, x_graph)
-    print(f"[config 5 full size] sd21 768^2 DDIM x2: image mean {float(img.mean()):.4f} std {float(img.std()):.4f}; "
-          f"graph vs eager latents rel {e:.2e}; engine {eng.memory_bytes() / 2 ** 30:.1f} GiB")
-    assert e < 1e-2
+    img_eager = eng.generate(lat, steps, gs, kind, use_graph=False)
+    # as at the tiny size: no reduction of the sampler step depends on arrival order (fixed-point GroupNorm statistics,
+    # split-K partials summed in a fixed order, forward attention without q-splits)
+    assert torch.equal(eng.x, x_graph) and torch.equal(img_eager, img), "graph replay must match the eager loop bit for bit"
+    # ---- oracle (CPU fp32, about a minute: 2 x 2 UNet forwards at 96x96 + the 768^2 decode) ----
+    ts = R.inference_timesteps(kind, steps)
+    with torch.no_grad():
+        negative = R.clip_plain(cwr, cfg.clip, neg.expand(B, -1)).half().float()
+        view = dict(p=sdv, w_enc=w_enc_v, norm_scale=norm, placeholder=torch.full((B,), phv), params=vparams, alpha=5.0)
+        embeds = []
+        for t in ts:
+            hs = R.text_conditioning(cwr, cfg.clip, sdo, w_enc, norm, ids, torch.full((B,), ph), torch.full((B,), t),
+                                     alpha=5.0, n_layers=cfg.unet.n_cross_layers, view=view)
+            embeds.append({k: (v.half().float() if k != "this_idx" else v) for k, v in hs.items()})
+        ref_img, ref_x = R.sd_pipeline_call(cfg, uwr, dwr, embeds, negative, lat, kind, steps, gs)
+    ex = _rel(x_graph, ref_x)
+    ei = (img.cpu() - ref_img.permute(0, 2, 3, 1)).abs().mean().item()
+    print(f"[config 5 full size] sd21 768^2 DDIM x{steps} vs oracle: final latents rel {ex:.3e}; image mean abs err {ei:.3e} "
+          f"(image mean {float(img.mean()):.4f} std {float(img.std()):.4f}); graph == eager; engine "
+          f"{eng.memory_bytes() / 2 ** 30:.1f} GiB")
+    assert ex < 1e-2 and ei < 2e-3

@@ -13,6 +13,7 @@ from view_neti_amd.compat.coach import Coach
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=60); ap.add_argument("--aug", type=int, default=0)
 ap.add_argument("--workers", type=int, default=4)
+ap.add_argument("--variants", default="host,device", help="which input pipelines to time (bench.py asks for `device` only)")
 a = ap.parse_args()
 tmp = tempfile.mkdtemp()
 root = os.path.join(tmp, "teapot"); os.makedirs(root)
@@ -20,6 +21,8 @@ rng = np.random.RandomState(0)
 for i in range(5):
     Image.fromarray(rng.randint(0, 255, (600, 800, 3), dtype=np.uint8)).save(os.path.join(root, f"{i}.jpg"))
 for name, device_pipe, workers in (("host pipeline", False, a.workers), ("device pipeline", True, 0)):
+    if name.split()[0] not in a.variants.split(","):
+        continue
     cfg = C.parse(C.RunConfig, ["--data.train_data_dir", root, "--data.placeholder_object_token", "<teapot>", "--learnable_mode", "0",
         "--model.word_embedding_dim", "768", "--model.arch_view_net", "15", "--model.arch_view_disable_tl", "False",
         "--model.arch_mlp_hidden_dims", "64", "--model.use_nested_dropout", "False", "--optim.max_train_steps", str(a.steps),
