@@ -281,42 +281,55 @@ __global__ __launch_bounds__(512) void lin_kernel(const GemmArgs g, const LinExt
       for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // one stage = 64 of K for the wave's 64 x (16 * NF) sub-tile, two k32 halves.  Per half and column block: four MFMAs, then
-  // the request for that B fragment's next-stage contents (unconditional: past the wave's last stage the offsets are out of
-  // range).  The A fragments of a half are read from the resident tile one half ahead (h = 1 at the top of the stage, h = 0
-  // of the NEXT stage between the halves).  The order is pinned with sched_barrier: left alone, hipcc sinks all ten loads
-  // below the last MFMA of the stage and the "stage of lead time" shrinks to a third of one.
+  // one stage = 64 of K for the wave's 64 x (16 * NF) sub-tile.  Per column block: eight MFMAs (both k32 halves), then the
+  // request for its two next-stage fragments TOGETHER — they are the two halves of the same 128-byte lines of 16 weight
+  // rows, so the second load finds the lines the first one has just asked for (requested half a stage apart, the other half
+  // came back from L2 a second time: twice the L2 -> L1 traffic of a kernel whose cost IS that traffic).  Unconditional:
+  // past the wave's last stage the offsets are out of range.  A fragments are read one stage ahead (two register buffers).
+  // The order is pinned with sched_barrier — left alone, hipcc sinks all loads below the last MFMA of the stage and the
+  // stage of lead time shrinks to a third.  k order inside a row is the tiled kernels': results are bit-identical to theirs.
 #define VN_SB() __builtin_amdgcn_sched_barrier(0)
-  half8 af0[MI], af1[MI];
+  half8 af[2][2][MI];  // [buffer][half][row block]
 #pragma unroll
-  for (int i = 0; i < MI; ++i) af0[i] = as_half8(*reinterpret_cast<const u32x4*>(smem + aoff0 + i * 2048));
-  for (int s = 0; s < my_nsub; ++s) {
-    for (int kt = 0; kt < KT; ++kt) {
-      const char* As = smem + kt * (BM * 128);
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af1[i] = as_half8(*reinterpret_cast<const u32x4*>(As + aoff1 + i * 2048));
-      VN_SB();
+    for (int i = 0; i < MI; ++i) af[0][h][i] = as_half8(*reinterpret_cast<const u32x4*>(smem + (h ? aoff1 : aoff0) + i * 2048));
+  auto stage = [&](auto cur_c, int kt) __attribute__((always_inline)) {
+    constexpr int cur = decltype(cur_c)::value;
+    const char* An = smem + (kt + 1 == KT ? 0 : kt + 1) * (BM * 128);
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[cur ^ 1][h][i] = as_half8(*reinterpret_cast<const u32x4*>(An + (h ? aoff1 : aoff0) + i * 2048));
+    VN_SB();
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           // operands swapped: D[row = n][col = m] => a lane owns 4 consecutive n of one m
-          acc[i][j] = VN_MFMA_16x16x32(bq[0][j], af0[i], acc[i][j], 0, 0, 0);
-        bq[0][j] = b_load(0, j);
-        VN_SB();
-      }
-      const char* An = smem + (kt + 1 == KT ? 0 : kt + 1) * (BM * 128);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af0[i] = as_half8(*reinterpret_cast<const u32x4*>(An + aoff0 + i * 2048));
+          acc[i][j] = VN_MFMA_16x16x32(bq[h][j], af[cur][h][i], acc[i][j], 0, 0, 0);
+      bq[0][j] = b_load(0, j);
+      bq[1][j] = b_load(1, j);
       VN_SB();
+    }
+    b_advance();
+  };
+  // (the A fragment buffers alternate by stage: K / 64 may be odd, so the k loop is unrolled by two with a tail)
+  for (int s = 0; s < my_nsub; ++s) {
+    int kt = 0;
+    for (; kt + 1 < KT; kt += 2) {
+      stage(std::integral_constant<int, 0>{}, kt);
+      stage(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < KT) {  // odd K / 64: the tail stage leaves the next sub-tile's first fragments in buffer 1
+      stage(std::integral_constant<int, 0>{}, kt);
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) acc[i][j] = VN_MFMA_16x16x32(bq[1][j], af1[i], acc[i][j], 0, 0, 0);
-        bq[1][j] = b_load(1, j);
-        VN_SB();
-      }
-      b_advance();
+        for (int i = 0; i < MI; ++i) af[0][h][i] = af[1][h][i];
     }
     epilogue();
     sub += LIN_WAVES;
