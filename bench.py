@@ -43,7 +43,7 @@ TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3
               10: "gemm_kernel<128,128,64,32,ring3>", 11: "gemm_kernel<128,64,64,32,ring3>", 12: "gemm_kernel<64,64,32,32,ring3>",
               13: "gemm_kernel<128,128,64,32,ring4>", 14: "gemm_kernel<128,64,64,32,ring4>", 15: "gemm_kernel<64,64,32,32,ring4>",
               16: "gemm8_kernel<256,256,8-phase>", 17: "gemm8_kernel<256,128,8-phase>",
-              18: "gemm8_kernel<256,128,8-phase,halo>", 19: "lin_kernel<64 rows x whole K resident, barrier-free column sweep>"}
+              18: "gemm8_kernel<256,128,8-phase,halo>"}
 # algorithmic FLOPs per sample at 512^2, SD-1.5: VAE 1116.7 + CLIP 16x13.3 + UNet fwd 803.3
 # + UNet dgrad 929.4 + CLIP dgrad 216 GF
 ALGO_GFLOP_PER_SAMPLE_512 = 3278.0
@@ -148,7 +148,7 @@ def pmc_traffic(tile_name: str):
     import glob
     import re
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.json")))
-    if not files or tile_name.startswith("lin_kernel"):
+    if not files:
         return {"traffic": None}
     dims = re.findall(r"\d+", tile_name.split(",ring")[0])
     stages = "3" if ",ring3" in tile_name else "4" if ",ring4" in tile_name else "2"

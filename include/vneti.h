@@ -84,11 +84,6 @@ typedef struct vneti_gemm_desc {
                          gather of the input gradient) with chunk-major K (conv_korder 1) on a 16-pixel grid: a block owns 16 x 16 output pixels and keeps the 18 x 18 input
                          patch of a 64-channel chunk in LDS for all nine taps (bit-identical to 17; split-K in whole 64-channel
                          chunks; other launches fall back to 17);
-                         19: the row-stationary persistent linear kernel (csrc/linear.hip) for short-K plain GEMMs (K <= 768,
-                         f16 out, one batch, no rowadd / gn_sums / split-K): a block keeps 64 rows of A for its whole K in
-                         LDS and its waves sweep the columns on their own, B straight from L2 into registers, no k-loop
-                         barrier; the only tile that takes the fused LayerNorm prologue (ln_gamma below); other launches
-                         fall back to the heuristic tile;
                          +100 selects the register-staged (non LDS-DMA) reference variant */
   /* split-K: f32 partials go to `workspace` (>= split_k*batch*M*N*4 bytes) and a second kernel
      reduces them and applies the epilogue.  split_k 0 = heuristic (only if a workspace is given),
@@ -129,15 +124,6 @@ typedef struct vneti_gemm_desc {
      channel in chunk): the nine taps of a chunk are consecutive k-steps, so the im2col re-reads of an input pixel
      hit L1/L2 instead of coming back after a whole channel sweep. */
   int conv_korder;
-  /* fused LayerNorm prologue (tile_hint 19 only; anything else is an error): A is the LayerNorm INPUT x [M][K] (f16) and the
-     product is LN(x) . B^T with LN(x) = ((x - mean) * rstd * ln_gamma + ln_beta) rounded to f16 — torch.nn.LayerNorm under
-     fp16 feeding a Linear (BasicTransformerBlock.norm1/2/3 -> attn.to_q/k/v, ff.net.0.proj).  ln_mean / ln_rstd
-     (f32 [M], optional) receive the row statistics vneti_layernorm_bwd needs; the normalised tensor is never stored. */
-  const float* ln_gamma;
-  const float* ln_beta;
-  float* ln_mean;
-  float* ln_rstd;
-  float ln_eps;
 } vneti_gemm_desc;
 
 int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream);

@@ -49,7 +49,7 @@ def check(name, got, ref, tol, elem_k=ELEM_K):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 101, 102, 103, 104, 105])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 101, 102, 103, 104, 105])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 128), (128, 64, 64), (77 * 4, 1280, 768), (1000, 8, 192)])
 def test_gemm_plain(hint, M, N, K):
     ops = _ops()
@@ -158,7 +158,7 @@ def test_gemm_epilogue_adds_round_like_f32(hint):
     assert torch.equal(fused, want)
 
 
-@pytest.mark.parametrize("hint", [3, 16, 17, 19])
+@pytest.mark.parametrize("hint", [3, 16, 17])
 @pytest.mark.parametrize("act", [1, 2, 3])
 @pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("N", [328, 324])
@@ -186,7 +186,7 @@ def test_gemm_gate_and_second_output(act, split, N, hint):
     check(f"gemm out2 act{act} split{split}", out2, fn(out.float().cpu()), 1e-3)
 
 
-@pytest.mark.parametrize("hint", [0, 1, 3, 5, 7, 10, 12, 16, 17, 19])
+@pytest.mark.parametrize("hint", [0, 1, 3, 5, 7, 10, 12, 16, 17])
 @pytest.mark.parametrize("M,C", [(300, 64), (1024, 320)])
 def test_gemm_geglu_epilogues(hint, M, C):
     """diffusers FeedForward GEGLU (h, g = proj(x).chunk(2); h * gelu(g)) fused into the GEMM epilogues

@@ -79,7 +79,3 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 // the 8-phase ping-pong tiles (gemm8.hip): 256 x bn, bn = 256 or 128 (halo: the 16 x 16-pixel halo-patch convolution form
 // of the 256 x 128 tile); g.ksplit / g.kt_per_split already set, f16 output only
 int vneti_launch_gemm8(void* gemm_args, int bn, int halo, hipStream_t st);
-// the row-stationary persistent linear kernel (linear.hip, tile_hint 19): short-K plain GEMMs, optional fused LayerNorm
-struct vneti_gemm_desc;
-int vneti_linear_eligible(const struct vneti_gemm_desc* d);
-int vneti_launch_linear(void* gemm_args, const struct vneti_gemm_desc* d, hipStream_t st);

@@ -797,10 +797,10 @@ int launch_cfg_f16(GemmArgs& g, hipStream_t st) {
 struct TileDims {
   int bm, bn;
 };
-constexpr int kMaxTile = 19;
+constexpr int kMaxTile = 18;
 constexpr TileDims kTiles[kMaxTile + 1] = {{0, 0},     {128, 128}, {128, 64},  {64, 64},  {256, 128}, {256, 256}, {256, 128}, {256, 128},
                                           {256, 128}, {128, 128}, {128, 128}, {128, 64},  {64, 64},   {128, 128}, {128, 64},  {64, 64},
-                                          {256, 256}, {256, 128}, {256, 128}, {64, 1 << 20} /* 19: 64 rows x the whole N, never split */};
+                                          {256, 256}, {256, 128}, {256, 128}};
 
 // tile heuristic: fill >= ~1.5 waves of the 256 CUs when possible, prefer the bigger tile
 int select_tile(int M, int N, int batch) {
@@ -836,7 +836,6 @@ extern "C" int vneti_gemm_select_split(int M, int N, int K, int batch, int tile_
   int cfg = tile_hint >= 100 ? tile_hint - 100 : tile_hint;
   if (cfg == 0) cfg = select_tile(M, N, batch);
   if (cfg < 1 || cfg > kMaxTile || K % 64 != 0) return -1;
-  if (cfg == 19) return 1;  // (an ineligible problem falls back to the heuristic tile: ask with tile_hint 0 for that)
   int ks = select_ksplit(M, N, K, batch, cfg, workspace_bytes / 4);
   const int nk = K / 64;
   if (ks > nk) ks = nk;
@@ -960,10 +959,6 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
     dma = false;
     cfg -= 100;
   }
-  // the row-stationary persistent linear kernel (linear.hip): short-K plain GEMMs; the one tile with the fused LayerNorm
-  VN_REQUIRE(!d->ln_gamma || (cfg == 19 && dma && vneti_linear_eligible(d)),
-             "gemm: the fused LayerNorm prologue needs tile_hint 19 and an eligible problem (plain f16 GEMM, K <= 768)");
-  if (cfg == 19 && (!dma || !vneti_linear_eligible(d))) cfg = 0;
   if (cfg == 0) cfg = select_tile(d->M, d->N, batch);
   VN_REQUIRE(cfg >= 1 && cfg <= kMaxTile, "gemm: unknown tile_hint %d", d->tile_hint);
   // the 8-phase tiles (16 / 17): LDS-DMA only; convolutions whose gather offset is linear in the tap (no fused upsample, no
@@ -984,7 +979,6 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
   if (cfg >= 10 && !dma) cfg = kTiles[cfg].bm == 128 ? (kTiles[cfg].bn == 128 ? 1 : 2) : 3;
   long long ws_floats = d->workspace ? d->workspace_bytes / 4 : 0;
   int ks = d->split_k;
-  if (cfg == 19) ks = 1;
   if (ks == 0) ks = select_ksplit(d->M, d->N, d->K, batch, cfg, ws_floats);
   if (ks < 1) ks = 1;
   const int nk = d->K / 64;
@@ -1030,7 +1024,6 @@ extern "C" int vneti_gemm_f16(const vneti_gemm_desc* d, void* stream) {
       launch_reduce(g, st);
       return vneti_check_launch("gemm8_kernel");
     }
-    case 19: return vneti_launch_linear(&g, d, st);
     default:
       return dma ? launch_cfg_f16<256, 256, 64, 64, true>(g, st) : launch_cfg_f16<256, 256, 64, 64, false>(g, st);
   }

@@ -130,7 +130,7 @@ class Schedule:
     _tile_cache: Dict[tuple, int] = {}
     _TILE_DIMS = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (256, 128), 5: (256, 256), 6: (256, 128), 7: (256, 128),
                   8: (256, 128), 9: (128, 128), 10: (128, 128), 11: (128, 64), 12: (64, 64), 13: (128, 128), 14: (128, 64),
-                  15: (64, 64), 16: (256, 256), 17: (256, 128), 18: (256, 128), 19: (64, 1 << 20)}
+                  15: (64, 64), 16: (256, 256), 17: (256, 128), 18: (256, 128)}
 
     @staticmethod
     def _gemm_key(f):
@@ -143,7 +143,7 @@ class Schedule:
         ck = (conv["mode"], conv["stride"], conv["ups"], conv["Hi"], conv["Wi"]) if conv else None
         return (M, N, K, kw.get("batch") or 1, ck, out.dtype == torch.float32, kw.get("geglu") or 0)
 
-    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), reps=8):
+    def autotune(self, candidates=(1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18), reps=8):
         """Measure, don't guess: time every distinct GEMM/conv problem of this schedule under each
         tile configuration, with the split-K heuristic and with split-K forced off (the f32 partials
         and the reduce launch are not always worth the extra blocks), and pin the fastest pair.  Launches are
@@ -202,19 +202,15 @@ class Schedule:
                         ([(h, 1) for h in candidates if h in (16, 17) or (h == 18 and halo_ok)] if try_cm else [])
                     if try_cm:
                         B_cm = packing._chunk_major(f.args[1], f.args[1].shape[0], conv["Ci"])
-                    lin_ok = not conv and key[3] == 1 and not key[5] and self.linear_ok(f.args[0], f.args[1]) \
-                        and f.keywords.get("rowadd") is None and f.keywords.get("gn_sums") is None and not f.keywords.get("act")
                     for h, ko in variants:
-                        if h == 19 and not lin_ok:  # (the library would run the heuristic tile: a duplicate measurement)
-                            continue
                         bm, bn = self._TILE_DIMS[h % 100]
                         tiles = -(-M_ // bm) * -(-N_ // bn) * key[3]
                         # 0 = library heuristic, 1 = no split, explicit factors where the grid leaves CUs idle and K is deep
                         sks = (0, 1) + (tuple(x for x in (2, 3, 4, 6, 8, 12)
                                               if x * 8 <= K_ // 64 and tiles * x <= 1024 and x * key[3] * M_ * N_ <= 16 * 2 ** 20)
                                         if tiles < 256 else ())
-                        if f.keywords.get("geglu") or h == 19:
-                            sks = (1,)  # the GEGLU epilogues do not exist in the split-K reduce kernel; tile 19 never splits
+                        if f.keywords.get("geglu"):
+                            sks = (1,)  # the GEGLU epilogues do not exist in the split-K reduce kernel
                         for sk in sks:
                             kw = dict(f.keywords)
                             kw["tile_hint"], kw["split_k"] = h, sk
@@ -490,32 +486,6 @@ class Schedule:
         y = self._buf((rows, Cc))
         self.fwd.append(partial(ops.layernorm_fwd, xv, y, rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], 1e-5))
         return y, rec
-
-    LIN_K_MAX = 768  # csrc/linear.hip: the row tile [64][K] stays in LDS for its whole K
-
-    @staticmethod
-    def linear_ok(xv, W) -> bool:
-        """can the row-stationary linear kernel (tile_hint 19) take x @ W^T?  (vneti_linear_eligible, minus the epilogue)"""
-        K = xv.shape[-1]
-        return xv.dtype == lib.act_dtype() and K % 64 == 0 and 64 <= K <= Schedule.LIN_K_MAX and W.shape[-2] % 8 == 0 \
-            and W.shape[-2] >= 16 and xv.stride(0) % 8 == 0
-
-    def _ln_gemm(self, xv, name, w, W, out, **kw):
-        """nn.LayerNorm feeding a Linear (BasicTransformerBlock.norm1/2/3 -> attn.to_q/k/v, ff.net.0.proj).  Where the
-        row-stationary kernel takes the problem the pair is ONE launch: the block normalises its resident [64][K] row tile
-        in LDS (the arithmetic of ln_fwd_kernel) and publishes mean / rstd for the backward; the normalised tensor never
-        reaches HBM.  Otherwise: the LayerNorm launch, then the GEMM.  Returns the record `_ln_bwd` consumes."""
-        import os
-        if not self.linear_ok(xv, W) or os.environ.get("VNETI_NO_LN_FUSE"):
-            n, rec = self._ln(xv, name, w)
-            self.fwd.append(partial(ops.gemm, n, W, out, **kw))
-            return rec
-        rows = xv.shape[0]
-        rec = dict(x=xv, gamma=self._w32(w[name + ".weight"]), beta=self._w32(w[name + ".bias"]),
-                   mean=self._buf((rows,), torch.float32), rstd=self._buf((rows,), torch.float32))
-        kw = dict(kw, tile_hint=19, split_k=1, ln=(rec["gamma"], rec["beta"], rec["mean"], rec["rstd"], 1e-5))
-        self.fwd.append(partial(ops.gemm, xv, W, out, **kw))
-        return rec
 
     def _ln_bwd(self, rec, dy, dx, accum, f16_copy=None):
         ops.layernorm_bwd(dy, rec["x"], rec["gamma"], rec["mean"], rec["rstd"], dx, accum=accum, f16_copy=f16_copy)

@@ -163,10 +163,11 @@ class UNetEngine(Schedule):
         h0 = self._buf((M, Cc))
         self.fwd.append(partial(ops.gemm, g, r["w_in"], h0, bias=b_in))
         # ---- attn1 (self) ----
+        n1, r["ln1"] = self._ln(h0, t + "norm1", w)
         wqkv = torch.cat([w[t + "attn1.to_q.weight"], w[t + "attn1.to_k.weight"], w[t + "attn1.to_v.weight"]], 0)
         r["wqkv"] = self._w16(wqkv)
         qkv = self._buf((M, 3 * Cc))
-        r["ln1"] = self._ln_gemm(h0, t + "norm1", w, r["wqkv"], qkv)  # norm1 -> to_q / to_k / to_v (one launch where K <= 768)
+        self.fwd.append(partial(ops.gemm, n1, r["wqkv"], qkv))
         q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
         o1 = self._buf((M, Cc))
         lse1 = self._buf((B, heads, N), torch.float32)
@@ -175,6 +176,7 @@ class UNetEngine(Schedule):
         h1 = self._buf((M, Cc))
         self.fwd.append(partial(ops.gemm, o1, r["wo1"], h1, bias=bo1, resid=h0))
         # ---- attn2 (XTI cross attention: K from ctx_k[layer], V from ctx_v[layer]) ----
+        n2, r["ln2"] = self._ln(h1, t + "norm2", w)
         r["wq2"] = self._w16(w[t + "attn2.to_q.weight"])
         run, slot = self.kv_slot[layer_idx]
         assert run["C"] == Cc, (name, layer_idx, Cc, run["C"])
@@ -182,7 +184,7 @@ class UNetEngine(Schedule):
         run["wv"][slot].copy_(w[t + "attn2.to_v.weight"])
         q2 = self._buf((M, Cc))
         k2, v2 = run["k"][slot], run["v"][slot]   # written by the batched prologue launches (_kv_fwd_ops)
-        r["ln2"] = self._ln_gemm(h1, t + "norm2", w, r["wq2"], q2)  # norm2 -> to_q
+        self.fwd.append(partial(ops.gemm, n2, r["wq2"], q2))
         o2 = self._buf((M, Cc))
         lse2 = self._buf((B, heads, N), torch.float32)
         self.fwd.append(partial(ops.attn_fwd, q2, k2, v2, o2, lse2, B, heads, N, L, D, scale, False))
@@ -190,6 +192,7 @@ class UNetEngine(Schedule):
         h2 = self._buf((M, Cc))
         self.fwd.append(partial(ops.gemm, o2, r["wo2"], h2, bias=bo2, resid=h1))
         # ---- feed-forward (GEGLU) ----
+        n3, r["ln3"] = self._ln(h2, t + "norm3", w)
         # GEGLU in the projection's epilogue: the rows of ff.net.0.proj are interleaved [h0..3 g0..3 h4..7 ...] at pack
         # time so a 16-byte chunk of the output tile holds matching halves; `p` (kept for the backward) stays in that
         # layout, `gg` = h * gelu(g) comes out of the same launch (no standalone geglu pass over the [M, 8C] tensor)
@@ -198,7 +201,7 @@ class UNetEngine(Schedule):
         r["wff2"], bff2 = self._w16(w[t + "ff.net.2.weight"]), self._w32(w[t + "ff.net.2.bias"])
         p = self._buf((M, 8 * Cc))
         gg = self._buf((M, 4 * Cc))
-        r["ln3"] = self._ln_gemm(h2, t + "norm3", w, r["wff1"], p, bias=bff1, out2=gg, geglu=1, split_k=1)  # norm3 -> ff.net.0
+        self.fwd.append(partial(ops.gemm, n3, r["wff1"], p, bias=bff1, out2=gg, geglu=1, split_k=1))
         h3 = self._buf((M, Cc))
         self.fwd.append(partial(ops.gemm, gg, r["wff2"], h3, bias=bff2, resid=h2))
         r["w_out"], b_out = self._w16(w[name + "proj_out.weight"].reshape(Cc, Cc)), self._w32(w[name + "proj_out.bias"])

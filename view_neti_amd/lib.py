@@ -90,7 +90,6 @@ class GemmDesc(C.Structure):
         ("gn_sums", c_vp), ("gn_hw", c_int), ("gn_cpg", c_int), ("gn_groups", c_int), ("gn_slots", c_int),
         ("geglu", c_int),
         ("conv_korder", c_int),
-        ("ln_gamma", c_vp), ("ln_beta", c_vp), ("ln_mean", c_vp), ("ln_rstd", c_vp), ("ln_eps", c_f),
     ]
 
 

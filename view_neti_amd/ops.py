@@ -43,10 +43,9 @@ def set_default_gemm_workspace(t):
 def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alpha=1.0, act=0,
          tile_hint=0, batch=0, strideA=0, strideB=0, strideC=0, M=None, N=None, K=None, conv=None,
          lda=None, ldc=None, workspace=None, split_k=0, gate=None, gate_act=0, out2=None, act2=0,
-         gn_sums=None, gn_hw=0, gn_groups=0, gn_slots=0, geglu=0, ln=None):
+         gn_sums=None, gn_hw=0, gn_groups=0, gn_slots=0, geglu=0):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T).  `conv` = dict(mode, Hi, Wi, Ci, Ho, Wo, stride,
-    pad_t, pad_l, ups, ldx) turns A into an implicit im2col view of an NHWC image.  `ln` = (gamma, beta, mean, rstd, eps):
-    A is a LayerNorm input and the product is LN(A) @ B^T (tile_hint 19, the row-stationary linear kernel, only)."""
+    pad_t, pad_l, ups, ldx) turns A into an implicit im2col view of an NHWC image."""
     d = _l.GemmDesc()
     d.A, d.B, d.C = _p(A), _p(B), _p(out)
     d.ldb = _ld(B)
@@ -84,8 +83,6 @@ def gemm(A, B, out, *, bias=None, rowadd=None, rows_per_group=1, resid=None, alp
         d.gn_sums, d.gn_hw, d.gn_groups, d.gn_slots = _p(gn_sums), gn_hw, gn_groups, gn_slots
         d.gn_cpg = d.N // gn_groups
     d.geglu = geglu  # 1: out2 = h * gelu(g) of the interleaved out; 2: out[M, 2N] = GEGLU backward against `gate`
-    if ln is not None:
-        d.ln_gamma, d.ln_beta, d.ln_mean, d.ln_rstd, d.ln_eps = _p(ln[0]), _p(ln[1]), _p(ln[2]), _p(ln[3]), float(ln[4])
     ws = workspace if workspace is not None else _default_ws
     if ws is not None:
         d.workspace = ws.data_ptr()
