@@ -1,5 +1,7 @@
 """End-to-end on the GPU through the reference-shaped surface: config -> Coach -> train -> checkpoints that
 load back (tiny SD shape family, synthetic image folder, gradient accumulation 2)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -379,3 +381,40 @@ def test_coach_mode1_view_mapper_only(tmp_path, monkeypatch):
     assert (out / "mapper-final_view.pt").exists() and not (out / "mapper-final_object.pt").exists()
     _, view = CheckpointHandler.load_mapper(out / "mapper-final_view.pt", "view")
     assert torch.equal(flatten_mapper_state(view.mapper_state()), eng.view_params_flat().cpu())
+
+
+def test_coach_vae_moment_cache(tmp_path):
+    """`--data.cache_vae_moments True` (extension): mode 0, augmentation_key 0 — every image is encoded once, later batches
+    replay the cached-moments graph; refused where the dataset is not deterministic."""
+    from view_neti_amd.compat import config as C
+    from view_neti_amd.compat.coach import Coach
+    root = tmp_path / "toys"
+    root.mkdir()
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 255, (90, 120, 3), dtype=np.uint8)).save(root / f"{i}.png")
+    base = ["--data.train_data_dir", str(root), "--data.placeholder_object_token", "<toy>", "--data.resolution", "64",
+            "--data.dataloader_num_workers", "0", "--model.word_embedding_dim", "128", "--model.arch_view_net", "15",
+            "--model.arch_view_disable_tl", "False", "--model.arch_mlp_hidden_dims", "64", "--model.use_nested_dropout", "False",
+            "--optim.max_train_steps", "6", "--optim.train_batch_size", "2", "--optim.gradient_accumulation_steps", "1",
+            "--optim.mixed_precision", "fp16", "--log.save_steps", "100", "--eval.validation_steps", "100",
+            "--data.cache_vae_moments", "True", "--log.exp_name", "run"]
+    cfg = C.parse(C.RunConfig, base + ["--log.exp_dir", str(tmp_path / "out")])
+    cfg.log.exp_dir = cfg.log.exp_dir / cfg.log.exp_name
+    cfg.log.logging_dir = cfg.log.exp_dir / cfg.log.logging_dir
+    torch.manual_seed(cfg.seed)
+    coach = Coach(cfg)
+    eng = coach.engine
+    assert eng.n_cache == 3
+    runs = [0]
+    fwd = eng.vae.forward
+    eng.vae.forward = lambda: (runs.__setitem__(0, runs[0] + 1), fwd())[1]
+    coach.train()
+    assert sorted(eng._cached_images) == [0, 1, 2] and eng.graph_a_c is not None
+    assert int(eng.opt_step.item()) == 6 and math.isfinite(eng.loss())
+    assert runs[0] <= 3, "the encoder ran eagerly more often than the capture's warm-up + trace passes allow"
+    cfg2 = C.parse(C.RunConfig, base + ["--log.exp_dir", str(tmp_path / "out2"), "--data.augmentation_key", "5"])
+    cfg2.log.exp_dir = cfg2.log.exp_dir / cfg2.log.exp_name
+    cfg2.log.logging_dir = cfg2.log.exp_dir / cfg2.log.logging_dir
+    with pytest.raises(ValueError, match="deterministic"):
+        Coach(cfg2)

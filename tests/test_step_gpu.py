@@ -436,3 +436,53 @@ def test_config4_at_size_88_scene_mappers():
     print(f"[config 4] scenes {scenes}: max |dp|/lr vs torch.optim.AdamW {err:.3e}; {ms:.1f} ms per micro-step "
           f"(bs {B}, 384x512, sd21) = {1e3 / ms:.1f} micro-steps/s; opt_step {eng.opt_step.item()}")
     assert err < 0.05 and eng.opt_step.item() == len(scenes)
+
+
+def test_vae_moment_cache_is_bit_identical_and_skips_the_encoder():
+    """data.cache_vae_moments (an extension, never the benchmark's configuration): with a deterministic
+    dataset the posterior moments of an image (vae.encode(...).latent_dist, training/coach.py:165) are kept in HBM and only
+    `.sample()` is re-drawn.  Same images, same noise => the same step bit for bit, with and without the cache, eager and
+    captured; a batch holding an image the cache has not seen runs the encoder."""
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.engine.step import TrainStepEngine
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    cfg = sc.tiny()
+    B, H, W = 2, 64, 64
+    torch.manual_seed(0)
+    sd = init_mapper_state(64, 64, cfg.clip.hidden_size)
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    images = [synth.gaussian((3, H, W), 40 + i).clamp(-1, 1) for i in range(5)]
+    ph = cfg.clip.vocab_size - 3
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size)
+    order = [(0, 1), (2, 3), (1, 0), (4, 2), (3, 3), (0, 4)]
+
+    def run(n_cache, graph):
+        eng = TrainStepEngine(cfg, synth.unet_weights(cfg.unet), synth.vae_weights(cfg.vae), synth.clip_weights(cfg.clip), B,
+                              H, W, sd, w_enc, 0.4, 0.2, lr=3e-3, seed=11, moment_cache_images=n_cache)
+        vae_runs = [0]
+        fwd = eng.vae.forward
+        eng.vae.forward = lambda: (vae_runs.__setitem__(0, vae_runs[0] + 1), fwd())[1]
+        losses = []
+        for step, pair in enumerate(order):
+            px = torch.stack([images[i] for i in pair])
+            eng.set_batch(px, ids, torch.full((B,), ph), image_idx=torch.tensor(pair) if n_cache else None)
+            if graph and step == 0:
+                eng.capture()
+            eng.step()
+            losses.append(eng.loss())
+        torch.cuda.synchronize()
+        return eng.params.clone(), losses, vae_runs[0], eng
+
+    p0, l0, runs0, _ = run(0, False)
+    p1, l1, runs1, e1 = run(5, False)
+    assert runs0 == len(order)
+    # batches 0, 1 and 3 bring new images; (1, 0), (3, 3) and (0, 4) are served from the cache
+    assert runs1 == 3 and sorted(e1._cached_images) == [0, 1, 2, 3, 4]
+    assert l0 == l1 and torch.equal(p0, p1), "the cached moments must reproduce the uncached step bit for bit"
+    p2, l2, _, e2 = run(5, True)
+    assert e2.graph_a_c is not None
+    assert l2 == l0 and torch.equal(p2, p0), "captured: full-step graph and cached-step graph interleaved"
+    with pytest.raises(ValueError, match="image_idx"):
+        e2.set_batch(torch.stack(images[:2]), ids, torch.full((B,), ph))
+    with pytest.raises(ValueError, match="outside"):
+        e2.set_batch(torch.stack(images[:2]), ids, torch.full((B,), ph), image_idx=[0, 5])

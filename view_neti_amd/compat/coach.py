@@ -113,7 +113,7 @@ class Coach:
             grad_accum=cfg.optim.gradient_accumulation_steps, hidden_object=first.hidden,
             unconstrained_object=m.bypass_unconstrained_object, unconstrained_view=m.bypass_unconstrained_view,
             nested_dropout_prob=m.nested_dropout_prob if m.use_nested_dropout else 0.0,
-            **first.engine_encoder_kwargs(), **kw)
+            moment_cache_images=self._moment_cache_size(), **first.engine_encoder_kwargs(), **kw)
         self.engine.set_lr(self.lr_schedule.lr(0))
         self.validator = None
         if cfg.eval.validation_prompts is not None and cfg.eval.validation_steps <= cfg.optim.max_train_steps \
@@ -143,6 +143,19 @@ class Coach:
             from ..engine.input_pipeline import DeviceImagePipeline
             _, _, ph, pw = self.engine.pixel_values.shape
             self.device_pipe = DeviceImagePipeline(ph, pw, device)
+
+    def _moment_cache_size(self) -> int:
+        """`data.cache_vae_moments` (extension): legal only where the pixels of dataset item i are the same
+        every time it comes up — augmentation_key 0 (no random crop / jitter / blur / rotation; flips are never enabled,
+        coach.py:682-702) and a flat image list (not the per-scene dict of learnable_mode 3)."""
+        d = self.cfg.data
+        if not getattr(d, "cache_vae_moments", False):
+            return 0
+        ds = self.train_dataset
+        if d.augmentation_key != 0 or not isinstance(ds.image_paths, (list, tuple)):
+            raise ValueError("data.cache_vae_moments needs a deterministic dataset: augmentation_key 0 and a single image "
+                             f"list (augmentation_key {d.augmentation_key}, learnable_mode {self.cfg.learnable_mode})")
+        return int(ds.num_images)
 
     def _pixels(self, batch):
         """host path: the collated f32 batch; device path (cfg.data.device_input_pipeline): the plans drawn by the
@@ -349,7 +362,8 @@ class Coach:
                     raise ValueError("a batch must hold a single object token (net_clip_text_embedding.py:67-68)")
                 eng.set_batch(self._pixels(batch), batch["input_ids"], ids_obj, batch["input_ids_placeholder_view"],
                               self._view_params(batch["input_ids_placeholder_view"]),
-                              object_index=self.object_slot.get(int(ids_obj[0]), 0))  # (-1 in mode 1: no object mapper)
+                              object_index=self.object_slot.get(int(ids_obj[0]), 0),  # (-1 in mode 1: no object mapper)
+                              image_idx=batch["image_idx"] if eng.n_cache else None)
                 if not captured:
                     eng.capture()
                     captured = True

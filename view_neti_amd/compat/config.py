@@ -68,6 +68,11 @@ class DataConfig:
     # extension (not in the reference): run resize / flip / augmentations as HIP kernels on images cached in HBM
     # (engine/input_pipeline.py); same random draws, same pixels as the host path
     device_input_pipeline: bool = field(default=False, metadata={"ext": True})
+    # extension (not in the reference): with augmentation_key 0 the dataset is deterministic (flip_p is never
+    # forwarded, coach.py:682-702 vs dataset.py:52), so `vae.encode(pixels).latent_dist` (coach.py:165) — the MOMENTS, not the
+    # sample — of an image is the same every time it comes up: keep them in HBM (64 KiB per 512^2 image) and re-draw only
+    # `.sample()`.  Bit-identical training; the VAE encoder runs once per image instead of once per step.
+    cache_vae_moments: bool = field(default=False, metadata={"ext": True})
     # filled at run time; a plain class attribute (NOT a dataclass field) as in the reference (config.py:64), so it
     # never enters config.yaml / the checkpoint's cfg dict
     placeholder_view_tokens = None

@@ -50,7 +50,8 @@ class TrainStepEngine:
                  unconstrained_object: bool = False, unconstrained_view: bool = False,
                  nested_dropout_prob: float = 0.0, hidden_object: int = 64,
                  legacy_pe_object: Optional[torch.Tensor] = None, enc_dim_object: int = 64,
-                 output_bypass_object: bool = True, output_bypass_view: bool = True, exchange=None):
+                 output_bypass_object: bool = True, output_bypass_view: bool = True, exchange=None,
+                 moment_cache_images: int = 0):
         """mapper_object: one mapper state_dict, or a list of them (learnable_mode 3: one object mapper per
         scene, `mapper_object_lookup`, training/coach.py:505-552) — `set_batch(object_index=k)` picks the one
         the batch trains."""
@@ -159,6 +160,17 @@ class TrainStepEngine:
         self.noise = torch.zeros(shape, dtype=torch.float32, device=device)
         self.latents = torch.zeros(shape, dtype=torch.float32, device=device)
         self.target = torch.zeros(shape, dtype=torch.float32, device=device)
+        # ---- optional cache of the VAE posterior moments per dataset image (deterministic datasets only: the CALLER vouches
+        # for that — compat/coach.py enables it for augmentation_key 0).  `latent_dist.sample()` is still drawn every step.
+        self.n_cache = int(moment_cache_images)
+        if self.n_cache:
+            hw2 = self.h * self.w
+            self.mcache = torch.zeros(self.n_cache, hw2, 2 * Lc, dtype=self.vae.moments.dtype, device=device)
+            self.img_idx = torch.zeros(batch, dtype=torch.int64, device=device)
+            self._cached_images = set()   # host mirror: which slots hold moments
+            self._batch_cached = False    # does the batch set by set_batch() consist of cached images only
+            self._batch_images = ()
+        self.graph_a_c = self.graph_acc_c = None  # the captured step without the VAE encoder (moments from the cache)
         self.need_backward = need_backward
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
@@ -169,7 +181,7 @@ class TrainStepEngine:
 
     # ------------------------------------------------------------------ inputs
     def set_batch(self, pixel_values, input_ids, placeholder_object, placeholder_view=None, view_params=None,
-                  object_index: int = 0):
+                  object_index: int = 0, image_idx=None):
         """object_index: which object mapper this batch trains (a batch is single-scene:
         models/net_clip_text_embedding.py:67-76 asserts one placeholder id and looks its mapper up)."""
         if not 0 <= object_index < self.n_objects:
@@ -180,6 +192,15 @@ class TrainStepEngine:
         self.obj_slot.fill_(object_index)
         if pixel_values is not None:  # None: the device input pipeline already wrote self.pixel_values
             self.pixel_values.copy_(pixel_values, non_blocking=True)
+        if self.n_cache:
+            if image_idx is None:
+                raise ValueError("the moment cache needs the dataset index of every image of the batch (image_idx)")
+            ids = tuple(int(i) for i in image_idx)
+            if min(ids) < 0 or max(ids) >= self.n_cache:
+                raise ValueError(f"image_idx {ids} outside the moment cache (0..{self.n_cache - 1})")
+            self.img_idx.copy_(torch.as_tensor(ids, dtype=torch.int64), non_blocking=True)
+            self._batch_images = ids
+            self._batch_cached = all(i in self._cached_images for i in ids)
         self.text.set_batch(input_ids, placeholder_object, placeholder_view, view_params)
 
     def train(self, mode: bool = True):
@@ -204,7 +225,9 @@ class TrainStepEngine:
         self.hyper[0] = lr
 
     # ------------------------------------------------------------------ the step
-    def forward_backward(self, accumulate: bool = False):
+    def forward_backward(self, accumulate: bool = False, cached: bool = False):
+        """cached: the batch's VAE moments come out of the moment cache (no encoder launches); otherwise the encoder runs
+        and, with a cache, its moments are stored at the batch's image slots."""
         B, Lc, hw = self.B, self.cfg.vae.latent_channels, self.h * self.w
         self.text.accumulate_grads = accumulate
         if self.device_rng:
@@ -220,7 +243,12 @@ class TrainStepEngine:
             with torch.cuda.stream(self.side):
                 self.text.forward()
                 self.unet.forward_pre()  # time embedding + the 32 context K/V projections
-        self.vae.forward()
+        if cached:
+            torch.index_select(self.mcache, 0, self.img_idx, out=self.vae.moments.view(B, hw, 2 * Lc))
+        else:
+            self.vae.forward()
+            if self.n_cache:
+                self.mcache.index_copy_(0, self.img_idx, self.vae.moments.view(B, hw, 2 * Lc))
         ops.sample_add_noise(self.vae.moments, self.eps, self.noise, self.timesteps, self.ac,
                              self.cfg.vae.scaling_factor, self.cfg.ddpm.prediction_type == "v_prediction", self.latents,
                              self.unet.x_in, self.target, B, Lc, hw)
@@ -271,9 +299,18 @@ class TrainStepEngine:
         host state (several object mappers pack the active scene's segment, chosen per step on the host)"""
         return self.world_size > 1 and self.exchange is not None and self.n_objects == 1
 
+    def _use_cache(self) -> bool:
+        """decided on the host per micro-batch; a batch that ran the encoder has its images in the cache afterwards"""
+        if not self.n_cache:
+            return False
+        if self._batch_cached:
+            return True
+        self._cached_images.update(self._batch_images)
+        return False
+
     def step_eager(self):
         """one micro-step; the optimizer runs after every `grad_accum`-th micro-step."""
-        self.forward_backward(accumulate=self.micro > 0)
+        self.forward_backward(accumulate=self.micro > 0, cached=self._use_cache())
         self.micro += 1
         if self.micro == self.grad_accum:
             self.micro = 0
@@ -321,6 +358,17 @@ class TrainStepEngine:
                 self.graph_acc = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_acc, stream=s):
                     self.forward_backward(accumulate=True)
+            if self.n_cache:  # the same steps with the moments read from the cache instead of the encoder
+                self.graph_a_c = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_a_c, stream=s):
+                    self.forward_backward(accumulate=False, cached=True)
+                    if fused_opt:
+                        self.all_reduce()
+                        self.optimizer_step()
+                if self.grad_accum > 1:
+                    self.graph_acc_c = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_acc_c, stream=s):
+                        self.forward_backward(accumulate=True, cached=True)
             if not fused_opt:
                 self.graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_b, stream=s):
@@ -337,7 +385,10 @@ class TrainStepEngine:
         """one micro-step (graph replay when captured); returns True when the optimizer stepped."""
         if self.graph_a is None:
             return self.step_eager()
-        (self.graph_a if self.micro == 0 else self.graph_acc).replay()
+        if self._use_cache():
+            (self.graph_a_c if self.micro == 0 else self.graph_acc_c).replay()
+        else:
+            (self.graph_a if self.micro == 0 else self.graph_acc).replay()
         self.micro += 1
         if self.micro < self.grad_accum:
             return False
