@@ -230,7 +230,7 @@ def _load_json(name):
         return json.load(f)
 
 
-_EXT_FIELDS = {"data": {"device_input_pipeline"}, "model": {"allow_synthetic_weights"}}
+_EXT_FIELDS = {"data": {"device_input_pipeline", "cache_vae_moments"}, "model": {"allow_synthetic_weights"}}
 
 
 def _strip_ext(d):
