@@ -240,7 +240,9 @@ def test_config_rejects_unknown_keys_and_keeps_ext_out_of_checkpoints():
     full, ref = C.encode(cfg), C.encode(cfg, include_ext=False)
     assert full["data"]["device_input_pipeline"] is True and "device_input_pipeline" not in ref["data"]
     assert "allow_synthetic_weights" not in ref["model"] and "placeholder_view_tokens" not in ref["data"]
-    assert C.ext_fields(cfg) == {"data.device_input_pipeline": True, "model.allow_synthetic_weights": True}
+    assert C.ext_fields(cfg) == {"data.device_input_pipeline": True, "data.cache_vae_moments": False,
+                                 "model.allow_synthetic_weights": True}
+    assert "cache_vae_moments" not in ref["data"]
     cfg.data.placeholder_view_tokens = ["<v>"]  # run-time attribute, never serialised (config.py:64 of the reference)
     assert "placeholder_view_tokens" not in C.encode(cfg)["data"]
 
