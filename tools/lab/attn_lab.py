@@ -1,4 +1,5 @@
-"""Lab: how the MFMA, VALU, LDS and staging parts of attn_fwd_kernel<40> add up (B=4, H=8, N=4096).  Builds
+"""[needs the lab switches: git apply tools/lab/attic/lab_switches.patch first — tools/lab/README.md]
+Lab: how the MFMA, VALU, LDS and staging parts of attn_fwd_kernel<40> add up (B=4, H=8, N=4096).  Builds
 csrc/attention.hip with -DVN_ATTN_LAB=<mask> into tools/lab/libvneti_attnlab_<mask>.so (results of those builds are garbage;
 only their duration means anything) and times the forward launch of each.
     python tools/lab/attn_lab.py build          (in the container)

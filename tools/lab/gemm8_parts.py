@@ -1,4 +1,5 @@
-"""Lab: what the 8-phase tiles' main loop waits for on the step's big convolutions.  Builds csrc/gemm8.hip with
+"""[needs the lab switches: git apply tools/lab/attic/lab_switches.patch first — tools/lab/README.md]
+Lab: what the 8-phase tiles' main loop waits for on the step's big convolutions.  Builds csrc/gemm8.hip with
 -DVN_GEMM8_LAB=<mask> (pieces of the loop removed; results are garbage, only durations mean anything) and times the
 512^2 x 128 -> 128 conv under the 256x128 tile and the 256^2 x 256 -> 256 conv under the 256x256 tile.
     python tools/lab/gemm8_parts.py build          (in the container)

@@ -1,4 +1,5 @@
-"""Lab: where a 256x256 8-phase tile spends its life.  Builds csrc/gemm8.hip with -DVN_GEMM8_STAMP into
+"""[needs the lab switches: git apply tools/lab/attic/lab_switches.patch first — tools/lab/README.md]
+Lab: where a 256x256 8-phase tile spends its life.  Builds csrc/gemm8.hip with -DVN_GEMM8_STAMP into
 tools/lab/libvneti_stamp.so (thread 0 of every block records s_memtime at: entry, first data landed, loop end, C tile
 in LDS, stores issued, stores acknowledged) and prints the per-section medians over the blocks of one launch.
     python tools/lab/gemm8_stamps.py build          (in the container)

@@ -1,4 +1,5 @@
-"""Lab: where a block of the generic GEMM tiles spends its life on the step's short-K linears, COLD (weights evicted, the
+"""[needs the lab switches: git apply tools/lab/attic/lab_switches.patch first — tools/lab/README.md]
+Lab: where a block of the generic GEMM tiles spends its life on the step's short-K linears, COLD (weights evicted, the
 activation operand re-touched: as inside the step).  Builds csrc/gemm_conv.hip with -DVN_GEMM_STAMP into
 tools/lab/libvneti_gstamp.so (thread 0 of every block records s_memtime at: entry, prologue DMAs issued, first stage landed,
 loop end, C tile in LDS, stores issued, stores acknowledged; 4-stage ring tiles 13 / 14 / 15 only) and prints per-section medians.

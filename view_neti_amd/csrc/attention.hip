@@ -58,12 +58,6 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // two f32 lanes per VALU instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): the softmax element work is what these
 // kernels spend their VALU cycles on, and the compiler does not pair the score scaling by itself.  Same roundings as the
 // scalar forms (one fused multiply-add; a subtract and a multiply).
-// tools/lab/attn_lab.py builds variants of attn_fwd_kernel with pieces removed (results are garbage) to see how the MFMA,
-// VALU, LDS and staging parts add up on the chip: bit 0 no softmax math, 1 no MFMAs, 2 no fragment reads from LDS,
-// 3 no staging (global loads / LDS writes), 4 no per-tile barrier, 5 no max pass.  0 in the product build.
-#ifndef VN_ATTN_LAB
-#define VN_ATTN_LAB 0
-#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -208,9 +202,8 @@ __global__ __launch_bounds__(256, (D <= 40 && QW == 1 ? 4 : 2)) void attn_fwd_ke
   }
   commit(0);
   __syncthreads();
-  constexpr int LAB = VN_ATTN_LAB;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (!(LAB & 8) && kt + 1 < nkt) issue(kt + 1);
+    if (kt + 1 < nkt) issue(kt + 1);
     const int key0 = kt * 64;
     const char* Ks = smem + (kt & 1) * STAGE;
     const char* Vs = Ks + KS_BYTES;
@@ -226,12 +219,11 @@ __global__ __launch_bounds__(256, (D <= 40 && QW == 1 ? 4 : 2)) void attn_fwd_ke
     for (int aa = 0; aa < 2; ++aa) {
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        half8 kf = (LAB & 4) ? qf[0][ks] : as_half8(
+        half8 kf = as_half8(
             *reinterpret_cast<const u32x4*>(Ks + (aa * 32 + l31) * C::ROW + (ks * 2 + h2) * 16));
 #pragma unroll
         for (int u = 0; u < QW; ++u) {
-          if constexpr (LAB & 2) asm volatile("" : "+v"(s[u][aa]) : "v"(kf));
-          else s[u][aa] = VN_MFMA_32x32x16(kf, qf[u][ks], s[u][aa], 0, 0, 0);
+          s[u][aa] = VN_MFMA_32x32x16(kf, qf[u][ks], s[u][aa], 0, 0, 0);
         }
       }
     }
@@ -253,8 +245,8 @@ __global__ __launch_bounds__(256, (D <= 40 && QW == 1 ? 4 : 2)) void attn_fwd_ke
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][aa][(LAB & 32) ? 0 : r]);
-      if (!(LAB & 32)) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][aa][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       if (!__all((mx - m[u]) * c <= RESCALE_THR_LOG2)) {
         // some row's max grew a lot (always true on the first tile): advance the running max and
         // rescale everything accumulated so far, exactly once
@@ -274,9 +266,8 @@ __global__ __launch_bounds__(256, (D <= 40 && QW == 1 ? 4 : 2)) void attn_fwd_ke
       for (int aa = 0; aa < 2; ++aa) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 t = (LAB & 1) ? f32x2{s[u][aa][r], s[u][aa][r + 1]}
-                                    : pk_fma(f32x2{s[u][aa][r], s[u][aa][r + 1]}, f32x2{c, c}, f32x2{-mc, -mc});
-          const float p0 = (LAB & 1) ? t.x : fast_exp2(t.x), p1 = (LAB & 1) ? t.y : fast_exp2(t.y);
+          const f32x2 t = pk_fma(f32x2{s[u][aa][r], s[u][aa][r + 1]}, f32x2{c, c}, f32x2{-mc, -mc});
+          const float p0 = fast_exp2(t.x), p1 = fast_exp2(t.y);
           s[u][aa][r] = p0;
           s[u][aa][r + 1] = p1;
           if constexpr (!ONES) psum += p0 + p1;
@@ -294,17 +285,16 @@ __global__ __launch_bounds__(256, (D <= 40 && QW == 1 ? 4 : 2)) void attn_fwd_ke
         for (int u = 0; u < QW; ++u) pf[u] = cvt8(s[u][aa], j);
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
-          half8 vf = (LAB & 4) ? qf[0][0] : load_tr(Vs, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
+          half8 vf = load_tr(Vs, C::ROW, db * 32, aa * 32 + 16 * j + 4 * h2, lane);
 #pragma unroll
           for (int u = 0; u < QW; ++u) {
-            if constexpr (LAB & 2) asm volatile("" : "+v"(o[u][db]) : "v"(vf), "v"(pf[u]));
-            else o[u][db] = VN_MFMA_32x32x16(vf, pf[u], o[u][db], 0, 0, 0);
+            o[u][db] = VN_MFMA_32x32x16(vf, pf[u], o[u][db], 0, 0, 0);
           }
         }
       }
     }
-    if (!(LAB & 8) && kt + 1 < nkt) commit((kt + 1) & 1);
-    if (!(LAB & 16)) __syncthreads();
+    if (kt + 1 < nkt) commit((kt + 1) & 1);
+    __syncthreads();
   }
 
 #pragma unroll

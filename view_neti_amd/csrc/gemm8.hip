@@ -39,24 +39,8 @@ constexpr int BM = 256, NT = 512;
 constexpr int HALF_BYTES = 128 * 128;  // an A half tile: 128 rows x 64 halfs
 constexpr int GN_IMG = 5;
 
-// lab build (-DVN_GEMM8_STAMP, tools/lab/gemm8_stamps.py): thread 0 of every block records s_memtime at the section
-// boundaries into the (otherwise unused) split-K workspace
-#ifdef VN_GEMM8_STAMP
-#define VN_STAMP(i)                                                                                       \
-  do {                                                                                                    \
-    if (tid == 0 && g.ws) reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define VN_STAMP(i)
-#endif
-
-// tools/lab/gemm8_parts.py builds variants with pieces of the main loop removed (results are garbage) to see what the loop
-// waits for: bit 0 no MFMAs, 1 no fragment reads, 2 no staging DMAs, 3 the A gather folded into a 256 KiB window (always
-// L2 hits).  0 in the product build.  (The switches that changed the synchronisation — no stagger, no waits, one phase per
-// K-tile, no priority — were removed in round 4 with their results recorded in DESIGN.md.)
-#ifndef VN_GEMM8_LAB
-#define VN_GEMM8_LAB 0
-#endif
+// (the lab switches of earlier rounds — per-section s_memtime stamps, removal experiments — live in
+// tools/lab/attic/lab_switches.patch; the product translation unit carries none)
 #define VN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define VN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -107,7 +91,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  VN_STAMP(0);
 
   // XCD-aware tile mapping (bijective for any tile count): consecutive ids on one XCD sweep N for a fixed M panel
   int nblk = g.tiles_m * g.tiles_n;
@@ -252,7 +235,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       nxt[j] = (a_mask[2 * h + j] & tapbit) ? (uint32_t)(a_base[2 * h + j] + soff) : VN_OOB;
-      if constexpr (VN_GEMM8_LAB & 8) nxt[j] &= 0x3FFFFu;
     }
     a_kt[h] += 1;
   };
@@ -271,12 +253,11 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     char* dst = smem + buf * BUF_BYTES + h * HALF_BYTES + wave * 1024;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      if (!(VN_GEMM8_LAB & 4)) dma16(rsA, dst + j * 8192, nxt[j]);
+      dma16(rsA, dst + j * 8192, nxt[j]);
   };
   auto issueB = [&](const int h, const int buf) {
     char* dst = smem + buf * BUF_BYTES + 2 * HALF_BYTES + h * HB_BYTES + wave * 1024;
-    if constexpr (VN_GEMM8_LAB & 4) {
-    } else if constexpr (BN == 256) {
+    if constexpr (BN == 256) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) dma16(rsB, dst + j * 8192, nxt[j]);
     } else {
@@ -297,36 +278,26 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     rdB[s] = 2 * HALF_BYTES + (wc * (16 * NJB) + frow) * 128 + ch;
   }
   half8 af[4][2], bf0[NJB][2], bf1[NJB][2];
-  if constexpr (VN_GEMM8_LAB & 2) {  // (lab build without fragment reads: defined, non-constant operands)
-    const half_t v = (half_t)(float)(lane & 3);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i][s] = half8{v, v, v, v, v, v, v, v};
-#pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) bf0[jb][s] = bf1[jb][s] = half8{v, v, v, v, v, v, v, v};
-    }
-  }
   auto readA = [&](const int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        if (!(VN_GEMM8_LAB & 2)) af[i][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdA[s] + h * HALF_BYTES + i * 2048));
+        af[i][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdA[s] + h * HALF_BYTES + i * 2048));
   };
   auto readB0 = [&](const int flip) {  // flip = BUF_BYTES: from the other K-tile buffer (BN = 256)
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        if (!(VN_GEMM8_LAB & 2)) bf0[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + (rdB[s] ^ flip) + jb * 2048));
+        bf0[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + (rdB[s] ^ flip) + jb * 2048));
   };
   auto readB1 = [&]() {
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        if (!(VN_GEMM8_LAB & 2)) bf1[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdB[s] + HB_BYTES + jb * 2048));
+        bf1[jb][s] = as_half8(*reinterpret_cast<const u32x4*>(smem + rdB[s] + HB_BYTES + jb * 2048));
   };
 
   // the bias of this lane's 16 columns, requested before the main loop (its L2 round trip would otherwise sit between
@@ -368,9 +339,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     __builtin_amdgcn_s_setprio(1);                                                                             \
     PREP;                                                                                                      \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                \
-        _Pragma("unroll") for (int jb = 0; jb < NJB; ++jb) if (VN_GEMM8_LAB & 1)                               \
-            asm volatile("" : "+v"(acc[H][J][i][jb]) : "v"(BF[jb][s]), "v"(af[i][s])); else acc[H][J][i][jb] = \
-            VN_MFMA_16x16x32(BF[jb][s], af[i][s], acc[H][J][i][jb], 0, 0, 0);           \
+        _Pragma("unroll") for (int jb = 0; jb < NJB; ++jb) acc[H][J][i][jb] =                                  \
+            VN_MFMA_16x16x32(BF[jb][s], af[i][s], acc[H][J][i][jb], 0, 0, 0);                                  \
     __builtin_amdgcn_s_setprio(0);                                                                             \
   } while (0)
 #define VN_PHASE_SYNC()                    \
@@ -392,12 +362,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     __builtin_amdgcn_s_setprio(1);                                                                             \
     PREP;                                                                                                      \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i) {              \
-      if (VN_GEMM8_LAB & 1) {                                                                                  \
-        asm volatile("" : "+v"(acc[H][0][i][0]), "+v"(acc[H][1][i][0]) : "v"(bf0[0][s]), "v"(bf1[0][s]), "v"(af[i][s])); \
-      } else {                                                                                                 \
-      acc[H][0][i][0] = VN_MFMA_16x16x32(bf0[0][s], af[i][s], acc[H][0][i][0], 0, 0, 0); \
-      acc[H][1][i][0] = VN_MFMA_16x16x32(bf1[0][s], af[i][s], acc[H][1][i][0], 0, 0, 0); \
-      }                                                                                                        \
+      acc[H][0][i][0] = VN_MFMA_16x16x32(bf0[0][s], af[i][s], acc[H][0][i][0], 0, 0, 0);                       \
+      acc[H][1][i][0] = VN_MFMA_16x16x32(bf1[0][s], af[i][s], acc[H][1][i][0], 0, 0, 0);                       \
     }                                                                                                          \
     __builtin_amdgcn_s_setprio(0);                                                                             \
   } while (0)
@@ -438,8 +404,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     }
     const int np_wave = wave == 0 ? 6 : 5;  // patch DMAs of this wave per chunk
     auto issueP = [&](const int j, const int chunk) {  // + chunk * 128 keeps an out-of-range offset out of range (< 2 GiB)
-      if (!(VN_GEMM8_LAB & 4))
-        dma16(rsA, smem + (chunk & 1) * PATCH_STRIDE + (j * 8 + wave) * 1024, pa_off[j] + (uint32_t)chunk * 128u);
+      dma16(rsA, smem + (chunk & 1) * PATCH_STRIDE + (j * 8 + wave) * 1024, pa_off[j] + (uint32_t)chunk * 128u);
     };
     // tap (dy, dx) of output pixel (y, x) reads patch pixel (y + dy, x + dx) in the forward gather and (y + 2 - dy,
     // x + 2 - dx) in the stride-1 transposed one (the patch starts one pixel up and left of the tile)
@@ -450,10 +415,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       auto issueBt = [&](const int kt, const int buf) {  // both 64-column halves of K-tile kt
         const uint32_t soff = (uint32_t)(kt_begin + kt) * 128u, dead = kt < T ? 0u : VN_OOB;
         char* dst = smem + BRING + buf * BBUF + wave * 1024;
-        if (!(VN_GEMM8_LAB & 4)) {
-          dma16(rsB, dst, (b_base[0] + soff) | dead);
-          dma16(rsB, dst + HB_BYTES, (b_base[2] + soff) | dead);
-        }
+        dma16(rsB, dst, (b_base[0] + soff) | dead);
+        dma16(rsB, dst + HB_BYTES, (b_base[2] + soff) | dead);
       };
       // fragment reads: lane (frow = pixel column of the tile row, fq = 8-channel chunk of the k32 sub-step)
       int lb[3];
@@ -461,14 +424,9 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       for (int dx = 0; dx < 3; ++dx) lb[dx] = (wr4 * 4) * PROW + (frow + dx) * 128 + ((fq ^ patch_key(frow + dx)) << 4);
       const int rb0 = (wc2 * 64 + frow) * 128 + ((fq ^ fkey) << 4);  // (sub-step 1: ^ 64 = chunk + 4)
       half8 bfh[4][2];  // the wave's four 16-column blocks of a B tile: read in Q0, held over both phases
-      if constexpr (VN_GEMM8_LAB & 2) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) bfh[cb][0] = bfh[cb][1] = af[0][0];
-      }
       auto readAh = [&](const int half, const int ab) {  // tile rows 2 * half, 2 * half + 1 of the wave's four, at tap offset ab
 #pragma unroll
         for (int i = 2 * half; i < 2 * half + 2; ++i) {
-          if (VN_GEMM8_LAB & 2) continue;
           af[i][0] = as_half8(*reinterpret_cast<const u32x4*>(smem + ab + i * PROW));
           af[i][1] = as_half8(*reinterpret_cast<const u32x4*>(smem + (ab ^ 64) + i * PROW));
         }
@@ -483,12 +441,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     PREP;                                                                                                      \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 2 * HALF; i < 2 * HALF + 2; ++i) \
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                     \
-      if (VN_GEMM8_LAB & 1) {                                                                                  \
-        asm volatile("" : "+v"(acc[cb >> 1][cb & 1][i][0]) : "v"(bfh[cb][s]), "v"(af[i][s]));                  \
-      } else {                                                                                                 \
-        acc[cb >> 1][cb & 1][i][0] =                                                                           \
-            VN_MFMA_16x16x32(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0);                       \
-      }                                                                                                        \
+      acc[cb >> 1][cb & 1][i][0] =                                                                             \
+          VN_MFMA_16x16x32(bfh[cb][s], af[i][s], acc[cb >> 1][cb & 1][i][0], 0, 0, 0);                         \
     }                                                                                                          \
     __builtin_amdgcn_s_setprio(0);                                                                             \
   } while (0)
@@ -518,7 +472,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       char* const bring = smem + BRING + wave * 1024;
       auto readBh = [&](const int slot) {  // slot: compile-time after unrolling
         const char* b = smem + BRING + slot * BBUF;
-        if (VN_GEMM8_LAB & 2) return;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
           bfh[cb][0] = as_half8(*reinterpret_cast<const u32x4*>(b + cb * 2048 + rb0));
@@ -534,7 +487,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       VN_WAIT_VM(2);  // patch 0 and B tile 0 have landed
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      VN_STAMP(1);
       if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
       __builtin_amdgcn_sched_barrier(0);
       // K-tile (chunk c, tap): Q0 reads the wave's four column blocks of B(t) and two of its four tile rows at the tap's
@@ -555,16 +507,13 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         readAh(0, ab);
         if constexpr (tap >= 1 && tap <= 6) {
           if (tap < 6 || w0) {
-            if (!(VN_GEMM8_LAB & 4))
-              dma16(rsA, smem + pslot + ((tap - 1) * 8) * 1024 + wave * 1024, last_chunk ? VN_OOB : pp[tap - 1]);
+            dma16(rsA, smem + pslot + ((tap - 1) * 8) * 1024 + wave * 1024, last_chunk ? VN_OOB : pp[tap - 1]);
           }
         }
         {
           const uint32_t dead = (last_chunk && tap >= 7) ? VN_OOB : 0u;
-          if (!(VN_GEMM8_LAB & 4)) {
-            dma16(rsB, bring + sslot * BBUF, bo0 | dead);
-            dma16(rsB, bring + sslot * BBUF + HB_BYTES, bo1 | dead);
-          }
+          dma16(rsB, bring + sslot * BBUF, bo0 | dead);
+          dma16(rsB, bring + sslot * BBUF + HB_BYTES, bo1 | dead);
           bo0 += 128u;
           bo1 += 128u;
         }
@@ -632,7 +581,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     VN_WAIT_VM(10);  // positions 0, 1 (B0, A0 of tile 0) have landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    VN_STAMP(1);
     readB0(0);
     VN_WAIT_LGKM0();  // retired before the stagger barrier: the slot is restaged in phase 1
     __builtin_amdgcn_sched_barrier(0);
@@ -691,7 +639,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
     VN_WAIT_VM(8);  // positions 0..3 (A0, B0, B1 of tile 0) have landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    VN_STAMP(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
     __builtin_amdgcn_sched_barrier(0);
     int stg = 2;  // buffer of the tile being staged: (t + 2) % 3
@@ -722,7 +669,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #undef VN_MMA2
 #undef VN_SYNC
   }
-  VN_STAMP(2);
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the (zero-filling) stagings past the end must have landed
   __syncthreads();                                                // before the epilogue reuses the buffers as its C tile
@@ -784,7 +730,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
           }
   }
   __syncthreads();
-  VN_STAMP(3);
 
   // ---- epilogue phase 2: coalesced row-major stores with the fused operands.  A thread owns one 8-column chunk
   // (column c = 8 * (tid % 32)) of rows tid / 32 + 16 * it, it = 0..15, handled U rows at a time: the C chunks (LDS) and
@@ -1020,11 +965,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       for (int w = 0; w < 4; ++w) atomicAdd(dst + w, src[w]);
     }
   }
-#ifdef VN_GEMM8_STAMP
-  VN_STAMP(4);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VN_STAMP(5);
-#endif
 }
 
 inline int epilogue_level8(const GemmArgs& g) {

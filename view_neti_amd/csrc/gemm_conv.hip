@@ -33,17 +33,6 @@
 
 namespace {
 
-// lab build (-DVN_GEMM_STAMP, tools/lab/gemm_stamps.py): thread 0 of every block records s_memtime at the section boundaries
-// into the (otherwise unused) split-K workspace
-#ifdef VN_GEMM_STAMP
-#define VN_GSTAMP(i)                                                                                                             \
-  do {                                                                                                                           \
-    if (threadIdx.x == 0 && g.ws && g.ksplit == 1) reinterpret_cast<unsigned long long*>(g.ws)[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define VN_GSTAMP(i)
-#endif
-
 // EPI selects how much of the fused epilogue is compiled in: 0 = bias + residual (most launches), 1 = + time-embedding
 // row-add and GroupNorm sums (the resnet convolutions, every VAE conv), 2 = + activation, gate, second output, GEGLU.
 // Every runtime-switched feature in the epilogue is paid by every launch (1-2 us x 575 launches per step, DESIGN.md
@@ -91,7 +80,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
   constexpr int GN_BYTES = (F32OUT || EPI == 0) ? 0 : GN_IMG * GN_NG * 4 * 8;  // [image][group][S1.hi S1.lo S2.hi S2.lo] 64-bit words
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + GN_BYTES];
 
-  VN_GSTAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -355,10 +343,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
     issue(kt_begin, 0, true);
     if (kt_begin + 1 < kt_end) issue(kt_begin + 1, 1, false);
     if (kt_begin + 2 < kt_end) issue(kt_begin + 2, 2, false);
-    VN_GSTAMP(1);
     wait_landed(kt_end - kt_begin - 1);
     __builtin_amdgcn_s_barrier();
-    VN_GSTAMP(2);
     load_frags(0, 0, 0);
     int st = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -395,7 +381,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
     }
   }
 
-  VN_GSTAMP(3);
   // ---- split-K: raw f32 partials straight to the workspace ---------------------------------
   if (g.ksplit > 1) {
     float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
@@ -448,7 +433,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
     }
   }
   __syncthreads();
-  VN_GSTAMP(4);
 
   // ---- epilogue phase 2: coalesced row-major stores with fused row-add / residual ------
   if constexpr (F32OUT) {
@@ -631,11 +615,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
       }
     }
   }
-#ifdef VN_GEMM_STAMP
-  VN_GSTAMP(5);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VN_GSTAMP(6);
-#endif
 }
 
 // split-K second pass: C = epi(alpha * sum_z ws[z]) with the same fused epilogue.
