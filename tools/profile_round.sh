@@ -17,7 +17,7 @@ rm -f $VNETI_AUTOTUNE_CACHE
 python $REPO/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json; echo
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- \
-  python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err
+  python $REPO/bench.py --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err
 # (the counter passes live in tools/pmc_round.sh: rocprofv3 + TCC counters segfaults around the whole bench process)
 python $REPO/tools/pmc_summary.py $TAG
 # the raw per-dispatch trace is tens of MB: keep only the summaries (gpurun copies back <= 64 MiB)

@@ -26,7 +26,7 @@ if os.path.exists(cache):
     env["VNETI_AUTOTUNE_CACHE"] = cache
 if not glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-                    os.path.join(repo, "bench.py"), "--steps", "6", "--warmup", "3", "--no-roofline", "--no-cpu-baseline"],
+                    os.path.join(repo, "bench.py"), "--steps", "6", "--warmup", "3", "--no-roofline", "--no-cpu-baseline", "--no-extras"],
                    cwd="/tmp", env=env, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 path = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = []
