@@ -33,7 +33,15 @@ def cost(f):
         causal = a[i + 6]
         mm = {ops.attn_fwd: 2, ops.attn_bwd_dq: 3, ops.attn_bwd_dkv: 4}[fn]  # matmuls of Nq x Nk x D executed
         name = {ops.attn_fwd: "attention fwd", ops.attn_bwd_dq: "attention bwd dQ", ops.attn_bwd_dkv: "attention bwd dK/dV"}[fn]
-        return (name, mm * 2.0 * Bn * H * Nq * Nk * D * (0.5 if causal else 1.0), 0)
+        scores = Bn * H * Nq * Nk * (0.5 if causal else 1.0)
+        # what the head dim allows: per score and SIMD, the MFMA cycles EXECUTED (32x32x16 = 32 cycles per
+        # 1024 scores and k-step; contractions over d pad to 16, output rows over d to 32) plus the VALU issue (2 cycles per
+        # wave64 instruction, v_exp_f32 at 5/3 of one: MI355X_MICROARCH.md) — the two pipes are observed to ADD on this part
+        ks, db = -(-D // 16), -(-D // 32)
+        mfma_c = {ops.attn_fwd: ks + 2 * db, ops.attn_bwd_dq: 2 * ks + 2 * db, ops.attn_bwd_dkv: 2 * ks + 4 * db}[fn] * 32 / 1024.0
+        valu_c = {ops.attn_fwd: 2.8, ops.attn_bwd_dq: 4.0, ops.attn_bwd_dkv: 4.0}[fn] * 2 / 64.0 + (2 * 5 / 3) / 64.0
+        cob = scores * (mfma_c + valu_c) / (1024 * 2.4e9)  # seconds: 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
+        return (name, mm * 2.0 * scores * D, 0, cob)
     if fn is ops.attn_bwd_small:  # (Q, K, V, dO, O, lse, dQ, dK, dV, Bn, H, N, D, scale, causal): S and dP in both roles + dQ, dK, dV
         Bn, H, N, D = a[9:13]
         return ("attention bwd (short sequences, one launch)", 7 * 2.0 * Bn * H * N * N * D * (0.5 if a[14] else 1.0), 0)
@@ -84,10 +92,12 @@ for f in launches:
         c = ("small launches (text path, RNG, layout glue)", 0,
              float(sum(t.numel() * t.element_size() for t in args if isinstance(t, torch.Tensor))) or 1.0)
     name = c[0]
-    d = classes.setdefault(name, dict(fs=[], flops=0.0, bytes=0.0))
+    d = classes.setdefault(name, dict(fs=[], flops=0.0, bytes=0.0, cob=0.0))
     d["fs"].append(f)
     if c:
         d["flops"] += c[1]; d["bytes"] += c[2]
+        if len(c) > 3:
+            d["cob"] += c[3]
 if os.environ.get("PER_LAUNCH"):
     # every HBM-bound launch by itself (events around each one, in schedule order), grouped by (class, bytes)
     import collections
@@ -135,6 +145,11 @@ for name, d in classes.items():
     if d["flops"]:
         r.update(bound="mfma", algorithmic_gflop=d["flops"] / 1e9, achieved=d["flops"] / (ms * 1e-3) / 1e12, peak=PF, unit="TFLOP/s")
         r["frac"] = r["achieved"] / PF
+        if d.get("cob"):
+            # the co-bound: the fraction of the MFMA peak this head-dim mix allows when the (padded) MFMA cycles and the
+            # softmax's VALU / exp issue serialise, and how much of THAT the kernels reach
+            r["cobound_frac_of_peak"] = d["flops"] / d["cob"] / 1e12 / PF
+            r["frac_of_cobound"] = d["cob"] / (ms * 1e-3)
     elif d["bytes"]:
         r.update(bound="hbm", algorithmic_mb=d["bytes"] / 1e6, achieved=d["bytes"] / (ms * 1e-3) / 1e12, peak=TB, unit="TB/s")
         r["frac"] = r["achieved"] / TB
@@ -146,6 +161,7 @@ print("|---|---|---|---|---|---|")
 for name, r in sorted(out.items(), key=lambda kv: -kv[1]["ms_per_step"]):
     if "frac" in r:
         costs = f"{r['algorithmic_gflop']/1e3:.2f} TFLOP" if r["bound"] == "mfma" else f"{r['algorithmic_mb']/1e3:.2f} GB"
-        print(f"| {name} | {r['launches']} | {r['ms_per_step']:.2f} | {costs} | {r['achieved']:.2f} {r['unit']} | {r['frac']:.2f} of {r['peak']:g} |")
+        extra = f" (co-bound {r['cobound_frac_of_peak']:.2f} of peak: at {r['frac_of_cobound']:.2f} of it)" if "frac_of_cobound" in r else ""
+        print(f"| {name} | {r['launches']} | {r['ms_per_step']:.2f} | {costs} | {r['achieved']:.2f} {r['unit']} | {r['frac']:.2f} of {r['peak']:g}{extra} |")
     else:
         print(f"| {name} | {r['launches']} | {r['ms_per_step']:.2f} | — | — | — |")
