@@ -1,12 +1,13 @@
-"""[needs tools/lab/attic/attn_fwd_wide.patch applied and the library rebuilt]
-Lab: the wide attention forward (one wave per SIMD, 128 queries per wave, AGPR accumulators; VNETI_ATTN_WIDE=1) against
-the product forward on the step's long self-attentions: bit-equality of O and lse, then interleaved timing."""
+"""Lab: an attention-forward variant behind an environment switch (argv[1], e.g. VNETI_ATTN_WIDE with
+tools/lab/attic/attn_fwd_wide.patch applied) against the product forward on the step's long self-attentions: bit-equality of O
+and lse, then interleaved timing.   python tools/lab/attn_env_ab.py VNETI_ATTN_WIDE"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from view_neti_amd import ops
 
 dev = "cuda"
+ENV = sys.argv[1] if len(sys.argv) > 1 else "VNETI_ATTN_WIDE"
 for (B, H, N, Nk, D) in [(4, 8, 4096, 4096, 40), (1, 8, 4096, 4096, 40), (4, 8, 4096, 77, 40), (2, 5, 4096, 4096, 64), (1, 5, 9216, 9216, 64), (2, 8, 2048, 1000, 40)]:
     C = H * D
     g = torch.Generator().manual_seed(N + D)
@@ -15,7 +16,7 @@ for (B, H, N, Nk, D) in [(4, 8, 4096, 4096, 40), (1, 8, 4096, 4096, 40), (4, 8, 
     sc = D ** -0.5
     outs = {}
     for wide in ("0", "1"):
-        os.environ["VNETI_ATTN_WIDE"] = wide
+        os.environ[ENV] = wide
         o = torch.full_like(q, 7.0); lse = torch.zeros(B, H, N, device=dev)
         ops.attn_fwd(q, k, v, o, lse, B, H, N, Nk, D, sc, False)
         torch.cuda.synchronize()
@@ -25,7 +26,7 @@ for (B, H, N, Nk, D) in [(4, 8, 4096, 4096, 40), (1, 8, 4096, 4096, 40), (4, 8, 
     ts = {"0": [], "1": []}
     for rnd in range(3):
         for wide in ("0", "1"):
-            os.environ["VNETI_ATTN_WIDE"] = wide
+            os.environ[ENV] = wide
             o, lse = outs[wide]
             for _ in range(2): ops.attn_fwd(q, k, v, o, lse, B, H, N, Nk, D, sc, False)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
