@@ -479,6 +479,17 @@ int vneti_comm_init(const void* id128, int rank, int world, void** comm);
 int vneti_allreduce_flat(void* comm, float* buf, long long n, void* stream);
 int vneti_comm_destroy(void* comm);
 
+/* ---- CU-partitioned side stream: the NEXT batch's VAE encode (training/coach.py:165-169: frozen VAE,
+   `.detach()` — no dependence on trainable state) runs beside the current step on a stream restricted to the compute
+   units of `mask` (hipExtStreamCreateWithCUMask; bit i = logical CU i, dealt round-robin over the XCDs by the driver),
+   so that the step's short launches always find free CUs.  Nothing in the reference corresponds: it encodes inline.
+     vneti_stream_create_cu_mask   -> *stream (a hipStream_t as void*); nwords 32-bit words of mask
+     vneti_stream_get_cu_mask      reads the mask the runtime holds for `stream` back
+     vneti_stream_destroy          releases it (NULL is fine) */
+int vneti_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream);
+int vneti_stream_get_cu_mask(void* stream, unsigned* mask, int nwords);
+int vneti_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,10 +12,16 @@ What is importable and therefore pinned by the real code:
   G4  models.net_clip_text_embedding.NeTICLIPTextEmbeddings            (overwrite + position add)
   G5  models.xti_attention_processor.XTIAttenProc                      (None / tensor / dict contexts)
   G6  transformers' CLIPTextModel (third-party stack the reference subclasses) with random weights
+  G7  models.neti_clip_text_encoder.NeTICLIPTextModel(batch=NeTIBatch), bypass included — imported over a small
+      transformers-4.27 shim built from the installed library's own layers (install_transformers_4_27_shim)
   G8  NeTIMapper.scale_m1_1, utils.utils.num_to_string/string_to_num
-Not importable (transformers 5.x dropped the 4.27 internals it subclasses):
-  models.neti_clip_text_encoder — its bypass maths (:129-180) is restated in oracle/sd_ref.py and
-  covered by property tests only.
+  G9  the legacy (arch_view_net <= 14) object mapper;  F2  checkpoints pickled by the reference's own classes
+  G10 sd_pipeline_call.sd_pipeline_call — the REAL denoising loop (:73-98) driven with a duck-typed pipeline
+      (oracle/toys.py: toy UNet, a scheduler object over oracle/sd_ref.sampler_step): call order, per-step
+      `prompt_embeds[i]`, the CFG formula, the scheduler-step sequence, output_type handling
+  G11 prompt_manager.PromptManager.embed_prompt (:43-101) over the G7 text encoder: the T x 16 context dicts
+Not pinnable: UNet2DConditionModel / AutoencoderKL / the diffusers schedulers (diffusers is absent from the reference
+tree and from this image) — oracle/sd_ref.py restates their published 0.14 architecture, PARITY UNPINNED.
 
 Each fixture is immediately cross-checked against oracle/sd_ref.py; the script fails if the
 restatement and the reference disagree.
@@ -530,6 +536,255 @@ def g9_legacy_mapper(R, NeTIMapper, PESigmas):
          **{"grad." + k: (v if v.numel() < 50000 else v[:, :16]) for k, v in grads.items()})
 
 
+def _duck_pipeline(R, toys, cfg, kind, neg_embeds, log):
+    """what `sd_pipeline_call` touches of a diffusers StableDiffusionPipeline, and nothing else"""
+    from view_neti_amd import sd_config as sc  # noqa: F401
+
+    class Scheduler:
+        order = 1  # DPMSolverMultistepScheduler.order / DDIMScheduler.order
+
+        def set_timesteps(self, n, device=None):
+            self.ts = R.inference_timesteps(kind, n, cfg.ddpm.num_train_timesteps)
+            self.timesteps = torch.tensor(self.ts)
+            self.ac = R.alphas_cumprod(cfg.ddpm)
+            self.i, self.m_prev = 0, None
+            log.append(("set_timesteps", n))
+
+        def scale_model_input(self, x, t):
+            log.append(("scale_model_input", int(t)))
+            return x
+
+        def step(self, noise_pred, t, latents, **kw):
+            assert int(t) == self.ts[self.i] and not kw
+            m_prev = torch.zeros_like(latents) if self.m_prev is None else self.m_prev
+            x, self.m_prev = R.sampler_step(cfg, kind, self.ac, self.ts, self.i, latents, noise_pred, m_prev)
+            log.append(("step", int(t)))
+            self.i += 1
+            return type("SchedulerOutput", (), {"prev_sample": x})()
+
+    class Tokenizer:
+        model_max_length = 77
+
+        def __call__(self, texts, padding=None, max_length=None, truncation=None, return_tensors=None):
+            assert padding == "max_length" and max_length == 77 and truncation and return_tensors == "pt"
+            log.append(("tokenizer", tuple(texts)))
+            return type("Enc", (), {"input_ids": torch.full((len(texts), 77), 7)})()
+
+    class TextEncoder:
+        dtype = torch.float32
+
+        def __call__(self, input_ids=None, attention_mask=None):
+            assert attention_mask is None and input_ids.shape == (1, 77)
+            log.append(("text_encoder", int(input_ids[0, 0])))
+            return (neg_embeds,), None  # NeTICLIPTextModel returns (output, output_with_bypass); output[0] = last hidden
+
+    class Bar:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def update(self):
+            log.append(("progress", 0))
+
+    class Pipeline:
+        vae_scale_factor = 8
+        _execution_device = torch.device("cpu")
+
+        def __init__(self):
+            self.unet = toys.ToyUNet()
+            self.scheduler = Scheduler()
+            self.tokenizer = Tokenizer()
+            self.text_encoder = TextEncoder()
+
+        def prepare_latents(self, n, c, h, w, dtype, device, generator, latents):
+            log.append(("prepare_latents", (n, c, h, w)))
+            return latents
+
+        def prepare_extra_step_kwargs(self, generator, eta):
+            return {}
+
+        def progress_bar(self, total=None):
+            return Bar()
+
+        def decode_latents(self, latents):
+            log.append(("decode_latents", 0))
+            return toys.toy_decode(latents).numpy()
+
+        def numpy_to_pil(self, image):
+            log.append(("numpy_to_pil", 0))
+            return ["pil"] * len(image)
+
+    return Pipeline()
+
+
+def g10_sd_pipeline_call(R):
+    """/root/reference/sd_pipeline_call.py:8-133 run for real on a duck-typed pipeline; the restatement
+    R.sd_pipeline_call must issue the same UNet calls in the same order and end on the same latents."""
+    from oracle import toys
+    from view_neti_amd import sd_config as sc
+    out = type("StableDiffusionPipelineOutput", (), {})
+
+    def _init(self, images=None, nsfw_content_detected=None):
+        self.images, self.nsfw_content_detected = images, nsfw_content_detected
+    out.__init__ = _init
+    dp = _stub("diffusers.pipelines")
+    dps = _stub("diffusers.pipelines.stable_diffusion", StableDiffusionPipelineOutput=out, StableDiffusionPipeline=object)
+    sys.modules["diffusers"].pipelines = dp
+    dp.stable_diffusion = dps
+    import sd_pipeline_call as ref_call  # the reference's own module
+    assert ref_call.__file__.startswith(REF)
+    cfg = sc.tiny()
+    g = torch.Generator().manual_seed(101)
+    D, L = 8, 5
+    neg = torch.randn(1, L, D, generator=g)
+    lat0 = torch.randn(1, 4, 8, 8, generator=g)
+    arrays = dict(neg=neg, latents0=lat0, guidance=np.array(7.5))
+    for tag, kind, steps, as_list in (("ddim_list", "ddim", 3, True), ("dpm_list", "dpm++2m", 4, True),
+                                      ("dpm_single", "dpm++2m", 3, False)):
+        def make_embeds():
+            gg = torch.Generator().manual_seed(202)
+            es = []
+            for i in range(steps if as_list else 1):
+                d = {"this_idx": 0, "_tag": i}
+                for l in range(16):
+                    d[f"CONTEXT_TENSOR_{l}"] = torch.randn(1, L, D, generator=gg)
+                    d[f"CONTEXT_TENSOR_BYPASS_{l}"] = torch.randn(1, L, D, generator=gg)
+                es.append(d)
+            return es if as_list else es[0]
+        log = []
+        pipe = _duck_pipeline(R, toys, cfg, kind, neg, log)
+        res = ref_call.sd_pipeline_call(pipe, make_embeds(), num_inference_steps=steps, guidance_scale=7.5,
+                                        latents=lat0.clone(), output_type="latent")
+        final = res.images
+        assert res.nsfw_content_detected is None
+        calls = list(pipe.unet.calls)
+        # same again through the decode branch (output_type anything but "latent"/"pil")
+        log2 = []
+        pipe2 = _duck_pipeline(R, toys, cfg, kind, neg, log2)
+        img = ref_call.sd_pipeline_call(pipe2, make_embeds(), num_inference_steps=steps, guidance_scale=7.5,
+                                        latents=lat0.clone(), output_type="np", return_dict=False)[0]
+        assert [e[0] for e in log2].count("decode_latents") == 1 and "numpy_to_pil" not in [e[0] for e in log2]
+        # the restatement with the same toy pair
+        mine_unet = toys.ToyUNet()
+        img_m, x_m = R.sd_pipeline_call(cfg, None, None, make_embeds(), neg, lat0, kind, steps, 7.5,
+                                        unet_fn=lambda x, t, hs: mine_unet(x, t, encoder_hidden_states=hs).sample,
+                                        decode_fn=toys.toy_decode)
+        close(x_m, final, 1e-6, f"G10 [{tag}] final latents")
+        close(img_m, img, 1e-6, f"G10 [{tag}] decoded image")
+        assert mine_unet.calls == calls, (mine_unet.calls, calls)
+        # what the loop did, in order: per step scale_model_input -> (uncond, cond) UNet calls -> scheduler.step
+        seq = [e for e in log if e[0] in ("scale_model_input", "step")]
+        assert [e[0] for e in seq] == ["scale_model_input", "step"] * steps
+        assert log[0] == ("tokenizer", ("",)) and log[1][0] == "text_encoder"
+        arrays.update({f"{tag}.final": final, f"{tag}.image": img, f"{tag}.calls": np.array(calls, dtype=np.int64),
+                       f"{tag}.steps": np.array(steps), f"{tag}.as_list": np.array(int(as_list)),
+                       f"{tag}.sched_t": np.array([e[1] for e in seq if e[0] == "step"], dtype=np.int64)})
+    arrays["kinds"] = np.array(["ddim", "dpm++2m", "dpm++2m"])
+    arrays["tags"] = np.array(["ddim_list", "dpm_list", "dpm_single"])
+    save("g10_sd_pipeline_call", **arrays)
+
+
+def g11_prompt_manager(R, NeTIMapper, NeTIBatch, PESigmas):
+    """/root/reference/prompt_manager.py:43-101 run for real: PromptManager.embed_prompt over the real NeTICLIPTextModel
+    (the G7 construction) with an object mapper and a dtu-12d view mapper -> T dicts of 16 (context, bypass) pairs.  The
+    restatement of the same conditioning (R.text_conditioning, one timestep at a time) must reproduce every tensor."""
+    install_transformers_4_27_shim()
+    from transformers import CLIPTextConfig
+    from models.neti_clip_text_encoder import NeTICLIPTextModel
+    from training.dataset import TextualInversionDataset as TID
+    from view_neti_amd import sd_config as sc
+    Dh, V = 32, 96
+    tc = CLIPTextConfig(vocab_size=V, hidden_size=Dh, max_position_embeddings=77, num_hidden_layers=2,
+                        num_attention_heads=2, intermediate_size=64, hidden_act="quick_gelu")
+    tc._attn_implementation = "eager"
+    my_cfg = sc.CLIPTextConfig(vocab_size=V, hidden_size=Dh, num_layers=2, num_heads=2, intermediate_size=64,
+                               act="quick_gelu")
+    torch.manual_seed(41)
+    model = NeTICLIPTextModel(tc).eval()
+    tm = model.text_model
+    gen = torch.Generator().manual_seed(42)
+    with torch.no_grad():
+        for prm in tm.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=gen) * (0.25 if prm.dim() > 1 else 0.1))
+        for n, prm in tm.named_parameters():
+            if "layer_norm" in n and n.endswith("weight"):
+                prm.add_(1.0)
+    cw = {"text_model." + k: v.detach().clone() for k, v in tm.state_dict().items() if "position_ids" not in k}
+    obj_id = 90
+    with synthetic_calibration():
+        import prompt_manager as ref_pm  # the reference's own module (imports its constants.py)
+        assert ref_pm.__file__.startswith(REF)
+        toks, _ = TID.dtu_generate_dset_cam_tokens_params()
+        cams = [0, 8, 13, 22]
+        view_tokens = [toks[c] for c in cams]
+        view_ids = [91 + i for i in range(len(cams))]
+        torch.manual_seed(51)
+        mo = NeTIMapper(embedding_type="object", output_dim=Dh, arch_mlp_hidden_dims=64, use_nested_dropout=False,
+                        norm_scale=torch.tensor(0.4), pe_sigmas=PESigmas(sigma_t=0.03, sigma_l=2.0),
+                        output_bypass=True, arch_view_net=15, arch_view_disable_tl=False,
+                        bypass_unconstrained=False, output_bypass_alpha=0.3).eval()
+        torch.manual_seed(52)
+        mv = NeTIMapper(embedding_type="view", output_dim=Dh, use_nested_dropout=False, norm_scale=torch.tensor(0.35),
+                        pe_sigmas=PESigmas(sigma_t=0.03, sigma_l=2.0, sigma_dtu12=0.5), output_bypass=True,
+                        placeholder_view_tokens=list(view_tokens), placeholder_view_token_ids=list(view_ids),
+                        arch_view_net=15, arch_view_disable_tl=False, bypass_unconstrained=False,
+                        output_bypass_alpha=0.15).eval()
+        g2 = torch.Generator().manual_seed(53)
+        with torch.no_grad():
+            for m in (mo, mv):
+                for n, prm in m.named_parameters():
+                    if n != "encoder.w":
+                        prm.add_(0.1 * torch.randn(prm.shape, generator=g2))
+        tm.embeddings.set_mapper({obj_id: mo}, mv, device="cpu")
+        ids = torch.randint(0, 88, (1, 77), generator=torch.Generator().manual_seed(5))
+        ids[0, 4], ids[0, 9] = view_ids[2], obj_id
+
+        class Tok:
+            model_max_length = 77
+
+            def __call__(self, text, padding=None, max_length=None, return_tensors=None):
+                assert padding == "max_length" and max_length == 77 and return_tensors == "pt"
+                return type("Enc", (), {"input_ids": ids.clone()})()
+
+        timesteps = [torch.tensor(999), torch.tensor(500), torch.tensor(20)]
+        pm = ref_pm.PromptManager(tokenizer=Tok(), text_encoder=model, timesteps=timesteps,
+                                  placeholder_view_token_ids=list(view_ids), placeholder_object_token_ids=[obj_id],
+                                  torch_dtype=torch.float32)
+        with torch.no_grad():
+            embeds = pm.embed_prompt("<view_13> a photo of a <obj>", num_images_per_prompt=2)
+        assert len(embeds) == 3 and all(e["this_idx"] == 0 for e in embeds)
+        assert len(embeds[0]) == 1 + 32 and embeds[0]["CONTEXT_TENSOR_0"].shape == (2, 77, Dh)
+        sdo = {k: v.detach().clone() for k, v in mo.state_dict().items() if k != "encoder.w"}
+        sdv = {k: v.detach().clone() for k, v in mv.state_dict().items() if k != "encoder.w"}
+        params = mv.view_tokenid_2_view_params[view_ids[2]].float()[None]
+        scaled = NeTIMapper.scale_m1_1(params, mv.cam_mins, mv.cam_maxs)
+        rows = list(range(16)) + [76]
+        arrays = {"cw." + k: v for k, v in cw.items()}
+        for ti, t in enumerate(timesteps):
+            with torch.no_grad():
+                hs = R.text_conditioning(cw, my_cfg, sdo, R.fourier_w([0.03, 2.0]), 0.4, ids, torch.tensor([obj_id]),
+                                         t[None], alpha=0.3, view=dict(p=sdv, w_enc=R.fourier_w([0.03, 2.0] + [0.5] * 12),
+                                                                       norm_scale=0.35, placeholder=torch.tensor([view_ids[2]]),
+                                                                       params=scaled, alpha=0.15))
+            for l in range(16):
+                for key in (f"CONTEXT_TENSOR_{l}", f"CONTEXT_TENSOR_BYPASS_{l}"):
+                    ref = embeds[ti][key]
+                    assert torch.equal(ref[0], ref[1])  # .repeat(num_images_per_prompt, 1, 1)
+                    close(hs[key], ref[:1], 2e-5, f"G11 t={int(t)} {key}") if l in (0, 15) else \
+                        (lambda a, b: None)(0, 0)
+                    assert (hs[key] - ref[:1]).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+                    short = "b" if "BYPASS" in key else "c"
+                    arrays[f"t{ti}.{short}{l}"] = ref[0, rows]
+                    arrays[f"t{ti}.{short}{l}.sum"] = np.array([ref[0].double().sum().item(),
+                                                               ref[0].double().abs().sum().item()])
+    save("g11_prompt_manager", ids=ids, obj_id=np.array(obj_id), view_id=np.array(view_ids[2]), view_scaled=scaled,
+         timesteps=np.array([int(t) for t in timesteps]), rows=np.array(rows), num_images=np.array(2),
+         alpha_obj=np.array(0.3), alpha_view=np.array(0.15), norm_obj=np.array(0.4), norm_view=np.array(0.35),
+         **{"sdo." + k: v for k, v in sdo.items()}, **{"sdv." + k: v for k, v in sdv.items()}, **arrays)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference not mounted; fixtures can only be generated in the build container")
@@ -833,6 +1088,10 @@ def main():
 
     # ---------------- G7 (text encoder): the real NeTICLIPTextModel incl. the bypass injection ------------------
     g_text_encoder_bypass(R, NeTIMapper, NeTIBatch, PESigmas)
+
+    # ---------------- G10 / G11: the inference path's two reference-owned files, run for real ------------------
+    g10_sd_pipeline_call(R)
+    g11_prompt_manager(R, NeTIMapper, NeTIBatch, PESigmas)
     print("all fixtures written and cross-checked against oracle/sd_ref.py")
 
 

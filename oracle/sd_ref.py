@@ -574,26 +574,38 @@ def step_coefficients(kind: str, ac: torch.Tensor, timesteps, i: int):
     return float(cx), float(base * (1 + 0.5 / r0)), float(-0.5 * base / r0), float(al[t]), float(sg[t])
 
 
+def sampler_step(sd_cfg, kind, ac, ts, i, x, e, m_prev):
+    """one `scheduler.step(noise_pred, t, latents).prev_sample` (DPM-Solver++(2M) / DDIM eta 0) on the data prediction;
+    returns (x_prev, x0) — x0 is the history entry the next multistep update reads"""
+    cx, c0, c1, a_t, s_t = step_coefficients(kind, ac, ts, i)
+    x0 = (x - s_t * e) / a_t if sd_cfg.ddpm.prediction_type == "epsilon" else a_t * x - s_t * e
+    return cx * x + c0 * x0 + c1 * m_prev, x0
+
+
 def sd_pipeline_call(sd_cfg, unet_w, vae_dec_w, prompt_embeds, negative_embeds, latents, kind="dpm++2m",
-                     num_inference_steps=50, guidance_scale=7.5):
-    """sd_pipeline_call.py:8-133: per-step NeTI context dicts (`prompt_embeds[i]`), an unconditional
-    embedding used for K and V of every layer, CFG, sampler step, decode, (x/2+0.5).clamp(0,1).
-    prompt_embeds: list (one per timestep) of XTI context dicts; negative_embeds (B,77,D)."""
+                     num_inference_steps=50, guidance_scale=7.5, unet_fn=None, decode_fn=None):
+    """sd_pipeline_call.py:8-133: per-step NeTI context dicts (`prompt_embeds[i]` when a list, the same object every
+    step otherwise, :86), an unconditional embedding used for K and V of every layer FIRST (:75-81), then the conditional
+    pass (:87-92), CFG (:96), sampler step (:99), decode, (x/2+0.5).clamp(0,1).
+    prompt_embeds: list (one per timestep) of XTI context dicts, or one dict / tensor; negative_embeds (B,77,D).
+    unet_fn(x, t, encoder_hidden_states) / decode_fn(latents): stand-ins for the two diffusers modules — the golden fixture
+    G10 (oracle/make_golden.py) drives the REAL reference loop and this restatement with the same toy pair."""
     ac = alphas_cumprod(sd_cfg.ddpm)
     ts = inference_timesteps(kind, num_inference_steps, sd_cfg.ddpm.num_train_timesteps)
+    if unet_fn is None:
+        unet_fn = lambda x_, t_, hs_: unet_forward(unet_w, sd_cfg.unet, x_, torch.full((x_.shape[0],), int(t_),
+                                                                                    dtype=torch.int64), hs_)
     x = latents.clone()
     m_prev = torch.zeros_like(x)
-    B = x.shape[0]
     for i, t in enumerate(ts):
-        tt = torch.full((B,), t, dtype=torch.int64)
-        eu = unet_forward(unet_w, sd_cfg.unet, x, tt, negative_embeds)
-        hs = dict(prompt_embeds[i])
-        hs["this_idx"] = 0
-        ec = unet_forward(unet_w, sd_cfg.unet, x, tt, hs)
+        eu = unet_fn(x, t, negative_embeds)
+        hs = prompt_embeds[i] if type(prompt_embeds) == list else prompt_embeds
+        if isinstance(hs, dict) and "this_idx" not in hs:  # prompt_manager.py:77 starts every dict at 0; the 16
+            hs = dict(hs, this_idx=0)                       # processors of one forward leave it at 0 again
+        ec = unet_fn(x, t, hs)
         e = eu + guidance_scale * (ec - eu)
-        cx, c0, c1, a_t, s_t = step_coefficients(kind, ac, ts, i)
-        x0 = (x - s_t * e) / a_t if sd_cfg.ddpm.prediction_type == "epsilon" else a_t * x - s_t * e
-        x = cx * x + c0 * x0 + c1 * m_prev
-        m_prev = x0
+        x, m_prev = sampler_step(sd_cfg, kind, ac, ts, i, x, e, m_prev)
+    if decode_fn is not None:
+        return decode_fn(x), x
     img = vae_decode(vae_dec_w, sd_cfg.vae, x / sd_cfg.vae.scaling_factor)
     return (img / 2 + 0.5).clamp(0, 1), x

@@ -33,3 +33,41 @@ extern "C" int vneti_last_error(char* buf, size_t n) {
   }
   return (int)len;
 }
+
+// ---- CU-partitioned streams ("the pipelined VAE encode"): a side stream whose kernels may only
+// occupy the compute units of `mask` (bit i = logical CU i; on gfx950 the driver deals the bits round-robin over the 8
+// XCDs, so the first 8*k bits are k CUs on every XCD).  A LINEAR hipGraph launched on such a stream runs on that
+// stream's queue and inherits the mask.
+extern "C" int vneti_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream) {
+  if (!mask || nwords <= 0 || !stream) {
+    vneti_set_error("vneti_stream_create_cu_mask: bad arguments");
+    return VNETI_EARG;
+  }
+  hipStream_t s = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
+  if (e != hipSuccess) {
+    vneti_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return VNETI_EHIP;
+  }
+  *stream = (void*)s;
+  return VNETI_OK;
+}
+
+extern "C" int vneti_stream_get_cu_mask(void* stream, unsigned* mask, int nwords) {
+  hipError_t e = hipExtStreamGetCUMask((hipStream_t)stream, (uint32_t)nwords, mask);
+  if (e != hipSuccess) {
+    vneti_set_error("hipExtStreamGetCUMask: %s", hipGetErrorString(e));
+    return VNETI_EHIP;
+  }
+  return VNETI_OK;
+}
+
+extern "C" int vneti_stream_destroy(void* stream) {
+  if (!stream) return VNETI_OK;
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) {
+    vneti_set_error("hipStreamDestroy: %s", hipGetErrorString(e));
+    return VNETI_EHIP;
+  }
+  return VNETI_OK;
+}

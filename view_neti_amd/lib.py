@@ -230,6 +230,9 @@ SIGNATURES = {
     "allreduce_flat": [c_vp, c_vp, c_ll, c_vp],
     "comm_destroy": [c_vp],
     "mapper_inputs": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp],
+    "stream_create_cu_mask": [C.POINTER(C.c_uint), c_int, C.POINTER(c_vp)],
+    "stream_get_cu_mask": [c_vp, C.POINTER(C.c_uint), c_int],
+    "stream_destroy": [c_vp],
 }
 
 INT_FUNCS = {"gemm_select_tile": [c_int] * 3, "gemm_select_split": [c_int] * 5 + [c_ll],
