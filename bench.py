@@ -35,6 +35,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+from view_neti_amd.roofline import gemm_cost  # noqa: E402,F401  (cost model shared with tools/kernel_roofline.py)
+
 MFMA_PEAK_TFLOPS = 2500.0  # fp16/bf16 dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_TBS = 8.0  # HBM3E spec peak, same guide
 TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3: "gemm_kernel<64,64,32,32>",
@@ -49,7 +51,7 @@ TILE_NAMES = {1: "gemm_kernel<128,128,64,64>", 2: "gemm_kernel<128,64,64,32>", 3
 ALGO_GFLOP_PER_SAMPLE_512 = 3278.0
 
 
-def build_engine(args, rank, world):
+def build_engine(args, rank, world, moment_cache: bool = False):
     from view_neti_amd import sd_config as sc, synth
     from view_neti_amd.engine.step import TrainStepEngine
     from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
@@ -73,33 +75,12 @@ def build_engine(args, rank, world):
     eng = TrainStepEngine(cfg, uw, vw, cw, args.batch, args.resolution, args.resolution, sd, w_enc, norm_scale, 0.2,
                           lr=lr, seed=1234 + rank, world_size=world, device_rng=True,
                           overlap=os.environ.get("VNETI_NO_OVERLAP", "0") != "1",
-                          moment_cache_images=args.batch if world == 1 and not getattr(args, "no_extras", True) else 0)
+                          moment_cache_images=args.batch if moment_cache else 0)
     del uw, vw, cw
     ids = synth.input_ids(args.batch, placeholder_id, cfg.clip.vocab_size)
     eng.set_batch(synth.pixel_values(args.batch, args.resolution, args.resolution, seed=1 + rank), ids,
                   torch.full((args.batch,), placeholder_id), image_idx=list(range(args.batch)) if eng.n_cache else None)
     return cfg, eng
-
-
-def gemm_cost(f):
-    """(M, N, K, batch, FLOPs, algorithmic HBM bytes, MFMA floor [s], HBM floor [s]) of one bound ops.gemm launch.
-    Bytes: every operand once — A (the plain matrix, or the NHWC image an implicit conv gathers from: NOT its 9x im2col
-    expansion), the weights, the output, plus the fused epilogue operands."""
-    kw = f.keywords
-    A, Bm = f.args[0], f.args[1]
-    M = kw.get("M") or A.shape[-2]
-    N, K = kw.get("N") or Bm.shape[-2], kw.get("K") or Bm.shape[-1]
-    batch = kw.get("batch") or 1
-    conv = kw.get("conv")
-    a_bytes = (M // (conv["Ho"] * conv["Wo"])) * conv["Hi"] * conv["Wi"] * conv["Ci"] * 2 if conv else M * K * 2 * batch
-    out = f.args[2]
-    c_cols = N * (2 if kw.get("geglu") == 2 else 1)
-    extra = sum(M * c * 2 for c, key in ((N, "resid"), (N, "out2"), (c_cols, "gate")) if kw.get(key) is not None)
-    if kw.get("geglu") == 1:
-        extra -= M * N  # out2 of the GEGLU projection is [M, N/2]
-    nbytes = a_bytes + N * K * 2 * batch + M * c_cols * out.element_size() * batch + extra
-    flops = 2.0 * M * N * K * batch
-    return M, N, K, batch, flops, nbytes, flops / (MFMA_PEAK_TFLOPS * 1e12), nbytes / (HBM_PEAK_TBS * 1e12)
 
 
 def roofline_pass(eng, reps=3):
@@ -178,17 +159,28 @@ def pmc_traffic(tile_name: str):
             a = targs(name)
             return "gemm_kernel" in name and "gemm8" not in name and a[:4] == dims[:4] and len(a) >= 7 and a[6] == stages
     try:
-        ks = json.load(open(files[-1]))["kernels"]
+        doc = json.load(open(files[-1]))
+        ks = doc["kernels"]
     except (OSError, ValueError, KeyError):
         return {"traffic": None}
+    # a counter figure belongs to the kernels it was collected on: quote it only when the file is stamped with THIS tree's
+    # kernel sources (tools/pmc_summary.py writes the stamp); otherwise the driver's record says null, not a stale number
+    from view_neti_amd.roofline import kernel_tree_sha
+    here = kernel_tree_sha()
+    if doc.get("kernel_tree_sha") != here:
+        return {"traffic": None, "traffic_source": os.path.basename(files[-1]),
+                "traffic_note": f"counter passes in {os.path.basename(files[-1])} were collected on kernel tree "
+                                f"{doc.get('kernel_tree_sha')}, this run's is {here}: not quoted"}
     hit = [e for name, e in ks.items() if match(name)]
     n = sum(e.get("launches", 1) for e in hit)
     if not hit or n == 0:
         return {"traffic": None}
     return {"traffic": sum(e["hbm_bytes"] * e.get("launches", 1) for e in hit) / n,
-            "traffic_source": os.path.basename(files[-1]),
+            "traffic_source": os.path.basename(files[-1]), "traffic_kernel_tree_sha": here,
             "traffic_note": "mean HBM bytes/launch over this tile's launches (all epilogue instantiations) in one eager "
-                            "train step (FETCH_SIZE x2 + WRITE_SIZE)"}
+                            "train step (FETCH_SIZE x2 + WRITE_SIZE), collected by the builder with tools/pmc_round.sh on "
+                            "the kernel tree named in traffic_kernel_tree_sha (= this run's); bench.py cannot run the "
+                            "separate --pmc passes itself"}
 
 
 def usable_cores(cap: int = 32) -> int:
@@ -313,7 +305,12 @@ def driver_timed_extras(cache_path):
     out = {}
     for key, cmd, field in (
             ("coach_steps_per_s", [os.path.join(ROOT, "tools", "bench_coach.py"), "--steps", "60", "--variants", "device"], "steps_per_s"),
-            ("infer_s_per_image_cfg5", [os.path.join(ROOT, "tools", "bench_infer.py"), "--steps", "50", "--reps", "1"], "s_per_image")):
+            ("infer_s_per_image_cfg5", [os.path.join(ROOT, "tools", "bench_infer.py"), "--steps", "50", "--reps", "1"], "s_per_image"),
+            # the reference's own evaluation configuration: width 768 x height 576, DPM-Solver++ 30 steps, CFG 7.5
+            # (training/validate.py:56-62,568-573; training/config.py eval.num_denoising_steps)
+            ("infer_s_per_image_eval_768x576_dpmpp30",
+             [os.path.join(ROOT, "tools", "bench_infer.py"), "--steps", "30", "--reps", "1", "--sampler", "dpm++2m",
+              "--height", "576", "--width", "768"], "s_per_image")):
         try:
             r = subprocess.run([sys.executable, *cmd], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -322,6 +319,26 @@ def driver_timed_extras(cache_path):
             out[key] = None
             out[key + "_error"] = f"{type(err).__name__}: {str(err)[:200]}"
     return out
+
+
+def moment_cache_extra(args, steps: int):
+    """NOT the headline: the same step with `data.cache_vae_moments` (mode 0, augmentation_key 0: the dataset is
+    deterministic and the VAE posterior moments of an image are cached), on an engine of its OWN built after
+    the headline's is gone — the headline engine carries no cache nodes, no extra graphs and no per-step host bookkeeping."""
+    _, eng = build_engine(args, 0, 1, moment_cache=True)
+    eng.capture()
+    for _ in range(6):  # the first step runs the encoder and fills the cache; afterwards every batch image is cached
+        eng.step()
+    assert eng._use_cache(), "the batch should be served from the moment cache by now"
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    torch.cuda.synchronize()
+    v = steps / (time.perf_counter() - t1)
+    del eng
+    torch.cuda.empty_cache()
+    return v
 
 
 def self_launch(n: int) -> int:
@@ -388,6 +405,10 @@ def main():
         import tempfile
         tune_cache = os.path.join(tempfile.gettempdir(), f"vneti_bench_picks_{os.getpid()}.json")
         os.environ["VNETI_AUTOTUNE_CACHE"] = tune_cache
+    if world > 1 and backend == "nccl" and not args.no_graph:
+        # N GPUs = the one-GPU graph + ONE collective node; a rank that silently fell back to [graph A -> host all-reduce ->
+        # graph B] would cost the scaling target and nobody would see why: make that an error (engine/step.py capture())
+        os.environ.setdefault("VNETI_REQUIRE_ONE_GRAPH", "1")
     cfg, eng = build_engine(args, rank, world)
     if not args.no_graph:
         eng.capture()
@@ -413,21 +434,18 @@ def main():
         rank_dts = [float(t.item()) for t in tall]
         dt = max(rank_dts)  # the contract's MAX over ranks
     loss = eng.loss()
-    # NOT the headline: the same step with `data.cache_vae_moments` (mode 0, augmentation_key 0: the dataset is deterministic
-    # and the VAE posterior moments of an image are cached).  The engine was built with a cache of one
-    # batch's images: the timed region above ran the full step (the batch is re-marked uncached before every replay), this
-    # loop replays the cached-moments graph.
-    cache_value = None
-    if getattr(eng, "n_cache", 0) and eng.graph_a_c is not None and world == 1:
-        eng._batch_cached = True
-        for _ in range(5):
-            eng.step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.step()
-        torch.cuda.synchronize()
-        cache_value = args.steps / (time.perf_counter() - t1)
+    # after the timed region: did every rank replay ONE schedule (rank 0's autotuner picks, parallel.shared_picks)?
+    picks_equal = None
+    if dist is not None:
+        import hashlib
+        from view_neti_amd import ops as _ops
+        picks = [(f.keywords.get("tile_hint"), f.keywords.get("split_k"), (f.keywords.get("conv") or {}).get("korder"))
+                 for f in eng.launches() if getattr(f, "func", None) is _ops.gemm]
+        digest = hashlib.sha256(repr(picks).encode()).hexdigest()
+        every = [None] * world
+        dist.all_gather_object(every, digest)
+        picks_equal = all(d_ == every[0] for d_ in every)
+    cache_value = None  # measured after the headline engine is released (moment_cache_extra)
 
     if rank == 0 and args.no_roofline:
         print(json.dumps({"value": world * args.steps / dt, "unit": "steps/s", "note": "roofline pass skipped"}))
@@ -453,7 +471,13 @@ def main():
                        "rank0_ms_per_step": dt_rank / args.steps * 1e3,
                        "rank_ms_per_step_min": min(rank_dts) / args.steps * 1e3,
                        "rank_ms_per_step_max": max(rank_dts) / args.steps * 1e3,
-                       "hipgraph": not args.no_graph, "final_loss": loss,
+                       "hipgraph": not args.no_graph,
+                       "exchange_in_graph": bool(eng.exchange_in_graph) if world > 1 else None,
+                       "exchange": (None if world == 1 else "vneti_allreduce_flat (library RCCL communicator, captured node)"
+                                    if eng.exchange_in_graph else "library RCCL communicator between two graphs"
+                                    if eng.exchange is not None else f"torch.distributed.all_reduce ({backend}) between two graphs"),
+                       "picks_identical_on_all_ranks": picks_equal,
+                       "final_loss": loss,
                        "algorithmic_tflop_per_step": ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512) ** 2 / 1e3,
                        "end_to_end_mfma_frac": ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512) ** 2 / 1e3
                                                / (ms * 1e-3) / MFMA_PEAK_TFLOPS,
@@ -478,15 +502,39 @@ def main():
                                                             "hbm_bound_launches": v["hbm_bound_launches"]}
                                             for k, v in rf.items()}},
         }
+        # every launch class of the step against ITS bound ("each kernel >= 60 %"), from this very run: one
+        # pass over the eager schedule with an event pair around every launch (view_neti_amd/roofline.py)
+        try:
+            from view_neti_amd.roofline import time_classes
+            cls = time_classes(eng.launches())
+            out["roofline"]["classes"] = {
+                k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
+                    if kk in ("launches", "ms_per_step", "bound", "achieved", "peak", "unit", "frac", "frac_of_cobound",
+                              "cobound_frac_of_peak")}
+                for k, v in sorted(cls.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+            out["roofline"]["classes_note"] = ("eager replay in schedule order, HIP events per launch, algorithmic FLOPs / bytes "
+                                               "per class; attention also against the builder's MFMA+VALU co-bound at 2.4 GHz")
+        except Exception as err:  # noqa: BLE001 (reported, never fatal for the metric)
+            out["roofline"]["classes"] = None
+            out["roofline"]["classes_error"] = f"{type(err).__name__}: {str(err)[:200]}"
         headline = (args.model, args.resolution, args.batch) == ("sd15", 512, 4)
         if world == 1 and (not args.no_cpu_baseline or (headline and not args.no_extras)):
             del eng
             torch.cuda.empty_cache()
         if world == 1 and headline and not args.no_extras and not args.no_cpu_baseline:
+            try:
+                out["config"]["steps_per_s_with_vae_moment_cache"] = moment_cache_extra(args, args.steps)
+            except Exception as err:  # noqa: BLE001
+                out["config"]["steps_per_s_with_vae_moment_cache_error"] = f"{type(err).__name__}: {str(err)[:200]}"
             out["config"].update(driver_timed_extras(tune_cache or os.environ.get("VNETI_AUTOTUNE_CACHE")))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_bounded(args)
         print(json.dumps(out))
+    if tune_cache:
+        try:
+            os.unlink(tune_cache)
+        except OSError:
+            pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -45,6 +45,25 @@ def test_bench_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
 
 
+@pytest.mark.timeout(1800)
+def test_bench_eight_ranks_on_one_gpu():
+    """the driver's SCALE run by construction (no 8-GPU node was ever available to the build): `bench.py --gpus 8` as eight
+    ranks (gloo, sharing cuda:0) — weak scaling: global batch 8 x per-GPU batch, value = 8 ranks' steps / MAX rank time,
+    every rank on rank 0's tile picks, per-rank timings populated, the exchange route named."""
+    port = 29900 + os.getpid() % 90
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+              "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "8", "--model", "tiny", "--resolution", "64",
+              "--batch", "2", "--steps", "3", "--warmup", "1"],
+             {"VNETI_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["parallelism"] == "dp8" and c["global_batch"] == 16 and c["rccl_ranks"] == 8
+    assert d["scaling"] == "weak" and abs(d["ms_per_step"] * d["value"] - 8000.0) < 8.0
+    assert c["picks_identical_on_all_ranks"] is True
+    assert 0 < c["rank_ms_per_step_min"] <= c["rank_ms_per_step_max"] and abs(c["rank_ms_per_step_max"] - d["ms_per_step"]) < 1e-6
+    assert c["exchange_in_graph"] is False and "gloo" in c["exchange"]  # the one-graph route needs the nccl backend
+    assert "cpu_baseline" not in d
+
+
 @pytest.mark.timeout(1200)
 def test_bench_self_launches_two_ranks():
     """the driver's own invocation: plain `python bench.py --gpus 2` (no launcher) must spawn the 2 ranks itself."""

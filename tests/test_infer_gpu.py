@@ -116,18 +116,81 @@ def test_pipeline_matches_oracle(cfg_name, kind, steps):
     assert ex < 2e-2 and ei < 1e-2
 
 
+@pytest.mark.parametrize("form", ["list", "dict", "tensor"])
+def test_sd_pipeline_call_accepts_the_reference_prompt_embeds_contract(form):
+    """/root/reference/sd_pipeline_call.py:86-92 + prompt_manager.py:79-99: `prompt_embeds` is what the reference's
+    PromptManager.embed_prompt returns — a list of T dicts {this_idx, CONTEXT_TENSOR_l, CONTEXT_TENSOR_BYPASS_l} — or one
+    dict / one tensor used at every step.  compat.sd_pipeline_call must take all three and reproduce the oracle's
+    restatement of the loop (itself pinned to the real file by golden fixture G10) on the same conditioning."""
+    from oracle import sd_ref as R
+    from view_neti_amd import sd_config as sc, synth
+    from view_neti_amd.compat.sd_pipeline_call import InferencePipeline, sd_pipeline_call
+    from view_neti_amd.compat.tokenizer import HashTokenizer
+    from view_neti_amd.engine.infer import InferenceEngine
+    from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
+    cfg = sc.tiny()
+    B, H, W, steps, kind, gs = 2, 64, 64, 4, "dpm++2m", 6.0
+    D = cfg.clip.hidden_size
+    uw, dw, cw = synth.unet_weights(cfg.unet), synth.vae_decoder_weights(cfg.vae), synth.clip_weights(cfg.clip)
+    gen = torch.Generator().manual_seed(19)
+    sdo = {k: v + 0.05 * torch.randn(v.shape, generator=gen) for k, v in init_mapper_state(64, 64, D).items()}
+    w_enc = fourier_frequencies([0.03, 2.0], 64, 0)
+    eng = InferenceEngine(cfg, uw, dw, cw, B, H, W, sdo, w_enc, 0.4, 0.2)
+    tok = HashTokenizer(cfg.clip.vocab_size)
+    pipe = InferencePipeline(eng, tok, sampler=kind)
+    r16 = lambda d: {k: (v.half().float() if v.dim() >= 2 and "embedding" not in k and not k.startswith("post_quant")
+                         else v) for k, v in d.items()}
+    uwr, dwr, cwr = r16(uw), r16(dw), r16(cw)
+    ph = cfg.clip.vocab_size - 3
+    ids = synth.input_ids(B, ph, cfg.clip.vocab_size)
+    ts = R.inference_timesteps(kind, steps)
+    with torch.no_grad():
+        neg_ids = tok([""], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        negative = R.clip_plain(cwr, cfg.clip, neg_ids.expand(B, -1)).half().float()
+        dicts = []
+        for t in ts:
+            hs = R.text_conditioning(cwr, cfg.clip, sdo, w_enc, 0.4, ids, torch.full((B,), ph), torch.full((B,), t),
+                                     alpha=0.2, n_layers=cfg.unet.n_cross_layers)
+            dicts.append({k: (v.half().float() if k != "this_idx" else v) for k, v in hs.items()})
+    embeds = {"list": dicts, "dict": dicts[1], "tensor": dicts[1]["CONTEXT_TENSOR_3"]}[form]
+    lat = synth.gaussian((B, 4, H // 8, W // 8), 23)
+    out = sd_pipeline_call(pipe, embeds, num_inference_steps=steps, guidance_scale=gs, num_images_per_prompt=B,
+                           latents=lat, output_type="latent")
+    x_gpu = out.images.cpu()
+    assert out.nsfw_content_detected is None
+    img = sd_pipeline_call(pipe, embeds, num_inference_steps=steps, guidance_scale=gs, num_images_per_prompt=B,
+                           latents=lat, output_type="np", return_dict=False)[0]
+    with torch.no_grad():
+        ref_img, ref_x = R.sd_pipeline_call(cfg, uwr, dwr, embeds, negative, lat, kind, steps, gs)
+    ex = _rel(x_gpu, ref_x)
+    ei = float(abs(torch.from_numpy(img) - ref_img.permute(0, 2, 3, 1)).mean())
+    print(f"[sd_pipeline_call, prompt_embeds as {form}] final latents rel {ex:.3e}; image mean abs err {ei:.3e}")
+    assert ex < 2e-2 and ei < 1e-2
+    if form == "list":
+        assert all(d["this_idx"] == 0 for d in dicts)
+        with pytest.raises(ValueError):
+            sd_pipeline_call(pipe, dicts[:2], num_inference_steps=steps, guidance_scale=gs, num_images_per_prompt=B,
+                             latents=lat, output_type="latent")
+    with pytest.raises(TypeError):
+        sd_pipeline_call(pipe, "a photo", num_inference_steps=steps, num_images_per_prompt=B, latents=lat)
+
+
 @pytest.mark.timeout(2400)
-def test_config5_full_size_sampler_step_and_decode():
-    """BASELINE config 5 at its real size (SD-2.1 shapes, 768x768, DDIM, CFG, object + pretrained-style view mapper)
-    AGAINST THE ORACLE: two sampler steps (each one CFG-batched UNet forward at the 96x96 latent: N = 9216, d = 64
-    self-attention) and the 768^2 VAE decode, compared with oracle/sd_ref.py's restatement of sd_pipeline_call
-    (sd_pipeline_call.py:73-98) on f16-rounded weights; the captured sampler step equals the eager one bit for bit."""
+@pytest.mark.parametrize("H,W,kind,steps", [(768, 768, "ddim", 2), (576, 768, "dpm++2m", 3)])
+def test_config5_full_size_sampler_step_and_decode(H, W, kind, steps):
+    """BASELINE config 5 at its real size (SD-2.1 shapes, 768x768, DDIM, CFG, object + pretrained-style view mapper) AND the
+    reference's own evaluation shape — width 768 x height 576, DPM-Solver++(2M), CFG 7.5
+    (/root/reference/training/validate.py:56-62,568-573; three steps so that the second-order multistep update runs) —
+    AGAINST THE ORACLE: sampler steps (each one CFG-batched UNet forward at the 96x96 / 72x96 latent: N = 9216 / 6912, d = 64
+    self-attention; the deepest level of the 72x96 case is 9x12 = 108 tokens, no multiple of any tile) and the VAE decode,
+    compared with oracle/sd_ref.py's restatement of sd_pipeline_call (sd_pipeline_call.py:73-98, pinned to the real loop by
+    fixture G10) on f16-rounded weights; the captured sampler step equals the eager one bit for bit."""
     from oracle import sd_ref as R
     from view_neti_amd import sd_config as sc, synth
     from view_neti_amd.engine.infer import InferenceEngine
     from view_neti_amd.mapper import fourier_frequencies, init_mapper_state
     cfg = sc.sd21()
-    B, H, W, steps, gs, kind = 1, 768, 768, 2, 7.5, "ddim"
+    B, gs = 1, 7.5
     D = cfg.clip.hidden_size
     dev = "cuda"
     uw, dw, cw = (synth.unet_weights(cfg.unet, device=dev), synth.vae_decoder_weights(cfg.vae, device=dev),
@@ -175,7 +238,7 @@ def test_config5_full_size_sampler_step_and_decode():
         ref_img, ref_x = R.sd_pipeline_call(cfg, uwr, dwr, embeds, negative, lat, kind, steps, gs)
     ex = _rel(x_graph, ref_x)
     ei = (img.cpu() - ref_img.permute(0, 2, 3, 1)).abs().mean().item()
-    print(f"[config 5 full size] sd21 768^2 DDIM x{steps} vs oracle: final latents rel {ex:.3e}; image mean abs err {ei:.3e} "
+    print(f"[config 5 full size] sd21 {W}x{H} {kind} x{steps} vs oracle: final latents rel {ex:.3e}; image mean abs err {ei:.3e} "
           f"(image mean {float(img.mean()):.4f} std {float(img.std()):.4f}); graph == eager; engine "
           f"{eng.memory_bytes() / 2 ** 30:.1f} GiB")
     assert ex < 1e-2 and ei < 2e-3

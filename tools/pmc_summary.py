@@ -51,6 +51,13 @@ for name, d in acc.items():
         e["write_bytes"] = 1024.0 * sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
     e["hbm_bytes"] = e.get("fetch_bytes", 0.0) + e.get("write_bytes", 0.0)
     out["kernels"][name] = e
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:  # stamp: which kernel sources these counters belong to (bench.py quotes `traffic` only for a matching tree)
+    from view_neti_amd.roofline import kernel_tree_sha
+    out["kernel_tree_sha"] = kernel_tree_sha()
+except Exception as err:  # noqa: BLE001
+    out["kernel_tree_sha"] = None
+    print("no kernel-tree stamp:", err)
 top = sorted(out["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes"] * kv[1]["launches"])[:40]
 out["kernels"] = dict(top)
 json.dump(out, open(os.path.join(root, f"{tag}_pmc.json"), "w"), indent=1)

@@ -2,7 +2,11 @@
 `view_neti_amd.engine.infer.InferenceEngine` instead of a diffusers `StableDiffusionPipeline`.
 
     pipeline        -> an `InferencePipeline` (engine + tokenizer; built once per resolution/batch)
-    prompt_embeds   -> the `PromptEmbeds` of `PromptManager.embed_prompt` (the reference passes the T dicts)
+    prompt_embeds   -> EITHER the reference's own contract (sd_pipeline_call.py:86-92): a list of T per-step XTI dicts
+                       (what the reference's PromptManager.embed_prompt returns, prompt_manager.py:79-99), one dict, or one
+                       (B, 77, D) tensor — fed straight to the UNet's per-layer K / V sources, the engine's text pass skipped;
+                       OR the light `PromptEmbeds` record of this package's PromptManager (conditioning computed inside
+                       the loop, 16 layers per launch schedule)
     height / width  -> fixed at engine construction; passing different values raises
     scheduler       -> `pipeline.sampler` ("dpm++2m" as installed by validate.py:568, or "ddim")
 Returns an object with `.images` (list of PIL images, `output_type="pil"`) or the array, like the reference.
@@ -10,7 +14,7 @@ Returns an object with `.images` (list of PIL images, `output_type="pil"`) or th
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, List, Optional, Union
+from typing import Any, Dict, List, Optional, Union
 
 import numpy as np
 import torch
@@ -42,7 +46,8 @@ def get_neg_prompt_input_ids(pipeline: InferencePipeline, negative_prompt: Optio
 
 
 @torch.no_grad()
-def sd_pipeline_call(pipeline: InferencePipeline, prompt_embeds: PromptEmbeds, height: Optional[int] = None,
+def sd_pipeline_call(pipeline: InferencePipeline, prompt_embeds: Union[PromptEmbeds, List[Dict[str, Any]], Dict[str, Any],
+                                                                       torch.Tensor], height: Optional[int] = None,
                      width: Optional[int] = None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
                      negative_prompt: Optional[Union[str, List[str]]] = None, num_images_per_prompt: Optional[int] = 1,
                      eta: float = 0.0, generator: Optional[torch.Generator] = None,
@@ -59,14 +64,22 @@ def sd_pipeline_call(pipeline: InferencePipeline, prompt_embeds: PromptEmbeds, h
         raise NotImplementedError("eta > 0 (stochastic DDIM) is not implemented")
     neg = get_neg_prompt_input_ids(pipeline, negative_prompt)
     eng.set_negative_prompt(neg.input_ids)
-    rep = lambda t: None if t is None else t.expand(B, *t.shape[1:]) if t.dim() > 1 else t.expand(B)
-    eng.set_prompt(rep(prompt_embeds.input_ids), rep(prompt_embeds.input_ids_placeholder_object),
-                   rep(prompt_embeds.input_ids_placeholder_view), rep(prompt_embeds.view_params),
-                   prompt_embeds.truncation_idx)
     if latents is None:  # pipeline.prepare_latents: randn(shape, generator) * init_noise_sigma (= 1)
         latents = torch.randn((B, eng.Lc, eng.h, eng.w), generator=generator, dtype=torch.float32)
-    out = eng.generate(latents.to(eng.dev), num_inference_steps, guidance_scale, pipeline.sampler,
-                       decode=output_type != "latent")
+    if isinstance(prompt_embeds, PromptEmbeds):
+        rep = lambda t: None if t is None else t.expand(B, *t.shape[1:]) if t.dim() > 1 else t.expand(B)
+        eng.set_prompt(rep(prompt_embeds.input_ids), rep(prompt_embeds.input_ids_placeholder_object),
+                       rep(prompt_embeds.input_ids_placeholder_view), rep(prompt_embeds.view_params),
+                       prompt_embeds.truncation_idx)
+        out = eng.generate(latents.to(eng.dev), num_inference_steps, guidance_scale, pipeline.sampler,
+                           decode=output_type != "latent")
+    elif isinstance(prompt_embeds, (list, dict, torch.Tensor)):
+        # the reference's contract: conditioning computed by the caller, `prompt_embeds[i]` per step when a list (:86)
+        out = eng.generate_from_contexts(latents.to(eng.dev), prompt_embeds, num_inference_steps, guidance_scale,
+                                         pipeline.sampler, decode=output_type != "latent")
+    else:
+        raise TypeError(f"prompt_embeds of type {type(prompt_embeds).__name__}: expected PromptEmbeds, a list of per-step "
+                        "context dicts, one dict or one tensor")
     if output_type == "latent":
         image, nsfw = out.clone(), None
     else:

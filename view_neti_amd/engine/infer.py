@@ -194,6 +194,70 @@ class InferenceEngine:
         self.decoder.forward()
         return self.image
 
+    # ------------------------------------------------------------------ the reference's own prompt_embeds contract
+    def load_contexts(self, embed) -> None:
+        """Write ONE step's conditional conditioning into the UNet's per-layer K / V sources, as the 16 XTIAttenProc
+        instances would read it (models/xti_attention_processor.py:27-41): a dict {CONTEXT_TENSOR_l ->  K source,
+        CONTEXT_TENSOR_BYPASS_l -> V source (absent: the former)} or one tensor used by every layer for both."""
+        B, L, nl = self.B, self.L, self.cfg.unet.n_cross_layers
+        ck, cv = self.unet.ctx_k[:, B * L:], self.unet.ctx_v[:, B * L:]
+
+        def rows(t):
+            t = torch.as_tensor(t)
+            if t.dim() == 2:
+                t = t[None]
+            if t.shape[0] == 1 and B > 1:
+                t = t.expand(B, *t.shape[1:])
+            if tuple(t.shape) != (B, L, ck.shape[-1]):
+                raise ValueError(f"context of shape {tuple(t.shape)}: expected ({B}, {L}, {ck.shape[-1]})")
+            return t.reshape(B * L, -1)
+
+        if isinstance(embed, dict):
+            for l in range(nl):
+                k = embed[f"CONTEXT_TENSOR_{l}"]
+                v = embed.get(f"CONTEXT_TENSOR_BYPASS_{l}", k)
+                ck[l].copy_(rows(k))
+                cv[l].copy_(rows(v))
+        else:
+            r = rows(embed)
+            for l in range(nl):
+                ck[l].copy_(r)
+                cv[l].copy_(r)
+
+    @torch.no_grad()
+    def generate_from_contexts(self, latents: torch.Tensor, prompt_embeds, num_inference_steps: int = 50,
+                               guidance_scale: float = 7.5, kind: str = "dpm++2m", decode: bool = True):
+        """`sd_pipeline_call` with the conditioning ALREADY computed, exactly as the reference passes it
+        (sd_pipeline_call.py:86: `prompt_embeds[i] if type(prompt_embeds) == list else prompt_embeds`): a list of T
+        per-step XTI dicts (PromptManager.embed_prompt's return value, prompt_manager.py:79-99), one dict, or one tensor.
+        The engine's own text pass is skipped; the negative prompt must have been set (set_negative_prompt)."""
+        if guidance_scale <= 1.0:
+            raise ValueError("sd_pipeline_call only defines the classifier-free-guidance branch (guidance_scale > 1)")
+        B = self.B
+        ts = inference_timesteps(kind, num_inference_steps, self.cfg.ddpm.num_train_timesteps)
+        if type(prompt_embeds) == list and len(prompt_embeds) < len(ts):
+            raise ValueError(f"{len(prompt_embeds)} per-step prompt embeddings for {len(ts)} sampler steps")
+        self.x.copy_(latents)
+        self.m_prev.zero_()
+        self.unet.x_in[:B].copy_(self.x)
+        self.unet.x_in[B:].copy_(self.x)
+        vpred = self.cfg.ddpm.prediction_type == "v_prediction"
+        if type(prompt_embeds) != list:
+            self.load_contexts(prompt_embeds)
+        for i, t in enumerate(ts):
+            if type(prompt_embeds) == list:
+                self.load_contexts(prompt_embeds[i])
+            self.unet.timesteps.fill_(t)
+            self.unet.forward()
+            cx, c0, c1, a_t, s_t = step_coefficients(kind, self.ac, ts, i)
+            ops.cfg_sampler_step(self.unet.pred, self.x, self.m_prev, self.unet.x_in, B, self.Lc, self.h * self.w,
+                                 guidance_scale, a_t, s_t, cx, c0, c1, vpred)
+        if not decode:
+            return self.x
+        self.decoder.z_in.copy_(self.x)
+        self.decoder.forward()
+        return self.image
+
     def _one_step(self, guidance_scale, vpred):
         B, L = self.B, self.L
         ops.table_fill_i64(self.t_text, self.ts_table, self.step_idx)

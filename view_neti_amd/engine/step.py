@@ -71,9 +71,11 @@ class TrainStepEngine:
             import torch.distributed as dist
             if os.environ.get("VNETI_RCCL_DIRECT", "1") != "0" and dist.is_initialized() and dist.get_backend() == "nccl":
                 from ..parallel import enable_direct_rccl
-                try:
+                try:  # the outcome is agreed over the process group (RcclComm): every rank raises, or none does
                     self.exchange = enable_direct_rccl()
                 except RuntimeError as err:  # loud, not fatal: torch's communicator does the same collective
+                    if os.environ.get("VNETI_REQUIRE_ONE_GRAPH", "0") == "1":
+                        raise
                     import warnings
                     warnings.warn(f"library RCCL communicator unavailable ({err}); using torch.distributed.all_reduce")
         self.device_rng = device_rng
@@ -300,17 +302,33 @@ class TrainStepEngine:
         return self.world_size > 1 and self.exchange is not None and self.n_objects == 1
 
     def _use_cache(self) -> bool:
-        """decided on the host per micro-batch; a batch that ran the encoder has its images in the cache afterwards"""
+        """decided on the host per micro-batch: does the batch consist of cached images only"""
+        return bool(self.n_cache) and self._batch_cached
+
+    def _mark_cached(self, used_cache: bool):
+        """after the micro-step is enqueued: a batch that ran the encoder has its images' moments in the cache (stream order
+        makes them visible to every later step).  Marking BEFORE the launch would leave stale slots behind a step that
+        failed to enqueue."""
+        if self.n_cache and not used_cache:
+            self._cached_images.update(self._batch_images)
+            self._batch_cached = bool(self._batch_images)  # the same batch again is served from the cache
+
+    def reset_moment_cache(self, image_idx=None):
+        """forget cached moments: all of them, or the listed dataset indices — for callers whose pixels behind an index
+        change (the cache is only as deterministic as the dataset the CALLER vouched for)"""
         if not self.n_cache:
-            return False
-        if self._batch_cached:
-            return True
-        self._cached_images.update(self._batch_images)
-        return False
+            return
+        if image_idx is None:
+            self._cached_images.clear()
+        else:
+            self._cached_images.difference_update(int(i) for i in image_idx)
+        self._batch_cached = all(i in self._cached_images for i in self._batch_images) and bool(self._batch_images)
 
     def step_eager(self):
         """one micro-step; the optimizer runs after every `grad_accum`-th micro-step."""
-        self.forward_backward(accumulate=self.micro > 0, cached=self._use_cache())
+        cached = self._use_cache()
+        self.forward_backward(accumulate=self.micro > 0, cached=cached)
+        self._mark_cached(cached)
         self.micro += 1
         if self.micro == self.grad_accum:
             self.micro = 0
@@ -325,21 +343,46 @@ class TrainStepEngine:
         bucket as one collective node,) fused AdamW — the launch list of N GPUs is the one-GPU list plus that node.
         Fallbacks keep the older shape [forward+backward] -> host-issued all-reduce -> [optimizer]: the gloo backend,
         several object mappers (host-dependent exchange plan), and a communicator that refuses capture."""
+        import os
+        want = self._exchange_capturable()
+        err = None
         try:
-            self._capture(self._exchange_capturable())
-        except RuntimeError as err:
-            if not self._exchange_capturable():
+            self._capture(want)
+        except RuntimeError as e:
+            if not want:
                 raise
-            import warnings
-            warnings.warn(f"capturing the RCCL all-reduce failed ({err}); the exchange runs between two graphs")
-            torch.cuda.synchronize()
-            self.graph_a = self.graph_b = self.graph_acc = None
-            self._capture(False)
+            err = e
+        if not want:
+            return
+        # the route is a COLLECTIVE decision: one rank replaying [graph A -> host all-reduce on torch's communicator ->
+        # graph B] beside ranks whose collective sits in their graph on the library's communicator would never pair up
+        from ..parallel import all_agree
+        if all_agree(err is None):
+            return
+        if os.environ.get("VNETI_REQUIRE_ONE_GRAPH", "0") == "1":
+            raise RuntimeError("VNETI_REQUIRE_ONE_GRAPH=1: the RCCL all-reduce could not be captured into the step's graph "
+                               f"on {'this' if err else 'another'} rank" + (f" ({err})" if err else ""))
+        import warnings
+        warnings.warn(f"capturing the RCCL all-reduce failed on {'this' if err else 'another'} rank"
+                      + (f" ({err})" if err else "") + "; every rank runs the exchange between two graphs")
+        torch.cuda.synchronize()
+        self.graph_a = self.graph_b = self.graph_acc = self.graph_a_c = self.graph_acc_c = None
+        self._capture(False)
 
     def _capture(self, exchange_in_graph: bool):
-        # the warm-up launches below are real steps: snapshot the trainable / RNG state and put it back
+        # the warm-up launches below are real steps: snapshot the trainable / RNG state and put it back — ALSO when the
+        # capture raises (the fallback re-captures from the same state, not from one optimizer step later)
         saved = (self.params, self.exp_avg, self.exp_avg_sq, self.opt_step, self.scaler, self.rng_state, self.seg_step)
         state = [t.clone() for t in saved]
+        try:
+            self._capture_graphs(exchange_in_graph)
+        finally:
+            torch.cuda.synchronize()
+            for dst, src in zip(saved, state):
+                dst.copy_(src)
+            self.micro = 0
+
+    def _capture_graphs(self, exchange_in_graph: bool):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -377,18 +420,20 @@ class TrainStepEngine:
                     self.optimizer_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        for dst, src in zip(saved, state):
-            dst.copy_(src)
-        self.micro = 0
 
     def step(self) -> bool:
         """one micro-step (graph replay when captured); returns True when the optimizer stepped."""
         if self.graph_a is None:
             return self.step_eager()
-        if self._use_cache():
+        if self.exchange_in_graph and getattr(self.exchange, "closed", False):
+            raise RuntimeError("the step's graph holds a collective on an RCCL communicator that has been closed (process "
+                               "group re-initialised?): rebuild the engine")
+        cached = self._use_cache()
+        if cached:
             (self.graph_a_c if self.micro == 0 else self.graph_acc_c).replay()
         else:
             (self.graph_a if self.micro == 0 else self.graph_acc).replay()
+        self._mark_cached(cached)
         self.micro += 1
         if self.micro < self.grad_accum:
             return False

@@ -25,26 +25,69 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
 
 
+def all_agree(ok: bool) -> bool:
+    """True on every rank iff `ok` is True on EVERY rank (one tiny MIN all-reduce over the process group; the identity
+    without one).  Every decision that changes which collectives a rank issues — the library communicator or torch's, the
+    exchange inside the step's graph or between two graphs — goes through this, so that ranks never disagree on the path
+    (a rank that falls back alone mis-pairs its collectives with the others' and the job deadlocks)."""
+    dist = _dist()
+    if dist is None:
+        return bool(ok)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
 class RcclComm:
     """An RCCL communicator behind the C ABI (include/vneti.h: vneti_comm_unique_id / vneti_comm_init /
     vneti_allreduce_flat / vneti_comm_destroy; csrc/comm.hip): the step's one exchange as a stream-ordered library call —
     what a binder of the C ABI that does not run torch.distributed uses, and capturable in the step's hipGraph.
     `exchange(obj)` must return rank 0's `obj` on every rank (any side channel: here torch.distributed's object broadcast
-    over the already initialised process group; a 128-byte id is all that crosses it)."""
+    over the already initialised process group; a 128-byte id is all that crosses it).
+    Construction is collective and its outcome is AGREED: if the id cannot be made on rank 0 or the initialisation fails on
+    any rank, every rank raises RuntimeError (and the ranks that did succeed release their handle)."""
 
-    def __init__(self, rank: int, world: int, exchange=None):
+    def __init__(self, rank: int, world: int, exchange=None, agree=None):
         import ctypes as C
         from . import lib
-        buf = C.create_string_buffer(128)
-        if rank == 0:
-            lib.call("comm_unique_id", buf)
-        uid = (exchange or share_from_rank0)(bytes(buf.raw) if rank == 0 else None)
-        self._h = C.c_void_p()
-        lib.call("comm_init", uid, rank, world, C.byref(self._h))
+        exchange = exchange or share_from_rank0
+        agree = agree or (all_agree if exchange is share_from_rank0 else (lambda ok: ok))
+        self._h = None
         self.rank, self.world = rank, world
+        msg = None
+        if rank == 0:  # a failure here must reach the other ranks, who are about to wait for the id
+            try:
+                buf = C.create_string_buffer(128)
+                lib.call("comm_unique_id", buf)
+                msg = bytes(buf.raw)
+            except RuntimeError as err:
+                msg = err
+        msg = exchange(msg)
+        if isinstance(msg, Exception):
+            raise RuntimeError(f"rank 0 could not create the RCCL id: {msg}")
+        h = C.c_void_p()
+        err = None
+        try:
+            lib.call("comm_init", msg, rank, world, C.byref(h))
+        except RuntimeError as e:
+            err = e
+        if not agree(err is None):
+            if err is None:
+                lib.call("comm_destroy", h)
+            raise RuntimeError(f"RCCL communicator initialisation failed on {'this' if err else 'another'} rank"
+                               + (f": {err}" if err else ""))
+        self._h = h
+
+    @property
+    def closed(self) -> bool:
+        return self._h is None
 
     def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
         from . import lib
+        if self._h is None:
+            raise RuntimeError("this RCCL communicator was closed (process group re-initialised or interpreter exit): an "
+                               "engine holding it — and any graph captured over it — must be rebuilt")
         assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.is_cuda
         lib.call("allreduce_flat", self._h, flat.data_ptr(), flat.numel(), torch.cuda.current_stream().cuda_stream)
         return flat
@@ -52,8 +95,8 @@ class RcclComm:
     def close(self):
         from . import lib
         if self._h:
-            lib.call("comm_destroy", self._h)
-            self._h = None
+            h, self._h = self._h, None
+            lib.call("comm_destroy", h)
 
 
 _direct: "RcclComm" = None  # set by enable_direct_rccl(): the exchange goes through vneti_allreduce_flat instead of torch
