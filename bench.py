@@ -74,7 +74,7 @@ def build_engine(args, rank, world, moment_cache: bool = False):
     lr = 1e-3 * args.batch * world  # scale_lr rule of training/coach.py:728-733 (accum = 1)
     eng = TrainStepEngine(cfg, uw, vw, cw, args.batch, args.resolution, args.resolution, sd, w_enc, norm_scale, 0.2,
                           lr=lr, seed=1234 + rank, world_size=world, device_rng=True,
-                          overlap=os.environ.get("VNETI_NO_OVERLAP", "0") != "1",
+                          overlap=os.environ.get("VNETI_OVERLAP", "0") == "1",  # lab switch; the product default is no fork
                           moment_cache_images=args.batch if moment_cache else 0)
     del uw, vw, cw
     ids = synth.input_ids(args.batch, placeholder_id, cfg.clip.vocab_size)

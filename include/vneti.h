@@ -479,10 +479,11 @@ int vneti_comm_init(const void* id128, int rank, int world, void** comm);
 int vneti_allreduce_flat(void* comm, float* buf, long long n, void* stream);
 int vneti_comm_destroy(void* comm);
 
-/* ---- CU-partitioned side stream: the NEXT batch's VAE encode (training/coach.py:165-169: frozen VAE,
-   `.detach()` — no dependence on trainable state) runs beside the current step on a stream restricted to the compute
-   units of `mask` (hipExtStreamCreateWithCUMask; bit i = logical CU i, dealt round-robin over the XCDs by the driver),
-   so that the step's short launches always find free CUs.  Nothing in the reference corresponds: it encodes inline.
+/* ---- CU-partitioned streams (measurement aid): a stream whose kernels may only occupy the
+   compute units of `mask` (hipExtStreamCreateWithCUMask; bit i = logical CU i, dealt round-robin over the XCDs by the driver).
+   Built to test whether the NEXT batch's VAE encode (training/coach.py:165-169: frozen VAE, `.detach()` — no dependence on
+   trainable state) hides beside the current step on a CU subset; measured: it does not (profiles/r06_cu_mask_probe.txt), so
+   nothing on the step's path uses these.  Nothing in the reference corresponds: it encodes inline.
      vneti_stream_create_cu_mask   -> *stream (a hipStream_t as void*); nwords 32-bit words of mask
      vneti_stream_get_cu_mask      reads the mask the runtime holds for `stream` back
      vneti_stream_destroy          releases it (NULL is fine) */

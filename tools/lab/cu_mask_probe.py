@@ -26,7 +26,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
 a = ap.parse_args()
 
-os.environ["VNETI_NO_OVERLAP"] = "1"  # linear graphs only: a graph with a fork takes runtime-internal (unmasked) streams
+os.environ["VNETI_OVERLAP"] = "0"  # linear graphs only (the product default since round 6): a graph with a fork takes runtime-internal (unmasked) streams
 args = argparse.Namespace(model="sd15", batch=4, resolution=512)
 _, eng = bench.build_engine(args, 0, 1)
 eng.step_eager()

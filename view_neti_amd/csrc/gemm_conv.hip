@@ -618,7 +618,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
 }
 
 // split-K second pass: C = epi(alpha * sum_z ws[z]) with the same fused epilogue.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(
+    // kernarg preload (as gemm_kernel above): what the index arithmetic and the first requests need, in SGPRs with the wave
+    float* p_ws, void* pC, const float* p_bias, const void* p_resid, const half_t* p_rowadd, int pM, int pN, int p_batch,
+    int p_ksplit, int p_ldc, int p_ldr, const GemmArgs gfull) {
+  GemmArgs g = gfull;
+  g.ws = p_ws;
+  g.C = pC;
+  g.bias = p_bias;
+  g.resid = p_resid;
+  g.rowadd = p_rowadd;
+  g.M = pM;
+  g.N = pN;
+  g.batch = p_batch;
+  g.ksplit = p_ksplit;
+  g.ldc = p_ldc;
+  g.ldr = p_ldr;
   // 32-bit index arithmetic (the launcher checks batch * M * ceil(N / 4) < 2^31): the 64-bit divisions this used to do cost
   // more than the reduction itself on the 110 launches per step, all of them a few microseconds long
   const unsigned n4 = (unsigned)(g.N + 3) / 4;
@@ -736,7 +751,8 @@ void launch_variant(const GemmArgs& g, dim3 grid, hipStream_t st) {
 inline void launch_reduce(const GemmArgs& g, hipStream_t st) {
   if (g.ksplit > 1) {
     long long total = (long long)g.batch * g.M * ((g.N + 3) / 4);  // < 2^31: checked with the workspace size in vneti_gemm_f16
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, g.ws, g.C, g.bias, g.resid,
+                       g.rowadd, g.M, g.N, g.batch, g.ksplit, (int)g.ldc, (int)g.ldr, g);
   }
 }
 

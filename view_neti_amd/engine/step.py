@@ -46,7 +46,7 @@ class TrainStepEngine:
                  n_view_params: int = 12, lr: float = 1e-3, betas=(0.9, 0.999), adam_eps: float = 1e-8,
                  weight_decay: float = 1e-2, loss_scale: Optional[float] = None, growth_interval: int = 2000,
                  seed: int = 0, world_size: int = 1, device_rng: bool = True, device: str = "cuda",
-                 need_backward: bool = True, grad_accum: int = 1, overlap: bool = True,
+                 need_backward: bool = True, grad_accum: int = 1, overlap: bool = False,
                  unconstrained_object: bool = False, unconstrained_view: bool = False,
                  nested_dropout_prob: float = 0.0, hidden_object: int = 64,
                  legacy_pe_object: Optional[torch.Tensor] = None, enc_dim_object: int = 64,
@@ -237,8 +237,11 @@ class TrainStepEngine:
             ops.rng_fill_randint(self.timesteps, self.cfg.ddpm.num_train_timesteps, self.rng_state, 0)
             ops.rng_fill_normal(self.eps, self.rng_state, 1)
             ops.rng_fill_normal(self.noise, self.rng_state, 2)
-        # fork: the 16 mapper+CLIP passes (many small launches) run beside the VAE encoder (few large
-        # ones) on a second stream; each schedule owns its split-K scratch, so they never alias
+        # overlap=True forks: the 16 mapper+CLIP passes (many small launches) run beside the VAE encoder (few large ones) on
+        # a second stream; each schedule owns its split-K scratch, so they never alias.  OFF by default since round 6: both
+        # sides fill the chip, and the two cross-stream edges of the captured graph cost more than the overlap returns
+        # (same box, alternating processes: 39.96 / 39.98 / 40.05 steps/s without the fork, 39.08 / 39.75 / 39.79 with it;
+        # profiles/r06_halo_persist_ab.txt) — the step is ONE linear chain of launches
         main = torch.cuda.current_stream()
         if self.overlap:
             self.side.wait_stream(main)

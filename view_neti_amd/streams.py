@@ -1,14 +1,20 @@
-"""CU-partitioned HIP streams (include/vneti.h: vneti_stream_create_cu_mask).
+"""CU-partitioned HIP streams (include/vneti.h: vneti_stream_create_cu_mask) — a MEASUREMENT aid, not on the step's path.
 
-The step's second consumer of the chip — the NEXT batch's VAE encode, which depends on no trainable state
-(training/coach.py:165-169: frozen VAE, `.detach()`) — runs on a stream whose kernels may only occupy a fixed subset of the
-256 compute units, so that a chip-filling encoder convolution can never take every CU away from the 10-20 us launches of the
-UNet's small levels (the failure of every earlier overlap experiment, profiles/LAB_NOTES.md round 2).
+Round 6 asked whether the NEXT batch's VAE encode — which depends on no trainable state (training/coach.py:165-169: frozen
+VAE, `.detach()`) — hides beside the current step when it runs on a stream whose kernels may only occupy a fixed subset of
+the 256 compute units, so that a chip-filling encoder convolution can never take every CU away from the 10-20 us launches of
+the UNet's small levels (the failure of every earlier overlap experiment, profiles/LAB_NOTES.md round 2).  Measured
+(tools/lab/cu_mask_probe.py, profiles/r06_cu_mask_probe.txt): the mask binds — a LINEAR hipGraph launched on a masked stream
+runs on that stream's queue, the VAE graph takes 15.5 / 10.9 / 8.2 ms on 64 / 96 / 128 CUs against 5.25 on the chip — and the
+pair [rest of the step || masked VAE] is never shorter than the sequential step (24.83 - 25.99 ms against 24.94): the work
+is conserved, the chip is power- and fill-bound as a whole, there is no idle capacity to harvest.  The step stays sequential.
 
-Mask convention (measured on gfx950, tools/lab/cu_mask_probe.py): bit i of the mask is logical CU i and the driver deals
-logical CUs round-robin over the 8 XCDs — bits 0..7 are CU 0 of XCD 0..7, bits 8..15 CU 1 of every XCD, and so on.
-`per_xcd_mask(k)` therefore keeps the XCDs balanced (k CUs on each), which the GEMM kernels' `block -> XCD = block % 8` tile
-order relies on; `whole_xcd_mask(n)` gives n complete XCDs instead.
+Mask convention (measured on gfx950): bit i of the mask is logical CU i and the driver deals logical CUs round-robin over the
+8 XCDs — bits 0..7 are CU 0 of XCD 0..7, bits 8..15 CU 1 of every XCD, and so on.  `per_xcd_mask(k)` therefore keeps the XCDs
+balanced (k CUs on each), which the GEMM kernels' `block -> XCD = block % 8` tile order relies on.  `whole_xcd_mask(n)` (bits
+i with i % 8 < n) does NOT confine work to n XCDs: a mask that leaves an XCD without any CU is not applied at all (the VAE
+graph ran at full speed under every such mask) — in SPX mode the dispatcher deals workgroups to all XCDs, an XCD cannot be
+masked out.  Kept because the probe documents exactly that.
 """
 from __future__ import annotations
 
@@ -32,7 +38,8 @@ def per_xcd_mask(k: int, first: int = 0) -> List[int]:
 
 
 def whole_xcd_mask(n: int, first: int = 0) -> List[int]:
-    """n complete XCDs (first .. first+n-1): bits i with i % 8 in that range"""
+    """bits i with first <= i % 8 < first + n, i.e. every CU of n XCDs and none of the others — measured NOT to bind (see the
+    module docstring): the runtime ignores a mask that empties an XCD"""
     if not 0 < n <= N_XCD - first:
         raise ValueError(f"whole_xcd_mask({n}, first={first}): the chip has {N_XCD} XCDs")
     return _words(i for i in range(N_CU) if first <= i % N_XCD < first + n)
