@@ -138,7 +138,9 @@ def test_bench_pmc_traffic_matches_the_tile_by_template_arguments(tmp_path, monk
         "void (anonymous namespace)::gemm_kernel<128, 128, 64, 32, false, true, 4, 0, false>((anonymous namespace)::GemmArgs)": {"launches": 108, "hbm_bytes": 45.3e6},
         "void (anonymous namespace)::gemm_kernel<128, 128, 64, 32, false, true, 2, 0, false>((anonymous namespace)::GemmArgs)": {"launches": 60, "hbm_bytes": 33.0e6},
     }
-    json.dump({"kernels": ks}, open(prof / "r99_pmc.json", "w"))
+    from view_neti_amd.roofline import kernel_tree_sha
+    # counters are quoted only for the kernel tree they were collected on (the stamp tools/pmc_summary.py writes)
+    json.dump({"kernels": ks, "kernel_tree_sha": kernel_tree_sha()}, open(prof / "r99_pmc.json", "w"))
     monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(tmp_path / "bench.py"))
     halo = bench.pmc_traffic(bench.TILE_NAMES[18])["traffic"]
     assert abs(halo - (28 * 166.8e6 + 25 * 163.9e6) / 53) < 1.0
@@ -146,6 +148,13 @@ def test_bench_pmc_traffic_matches_the_tile_by_template_arguments(tmp_path, monk
     assert abs(bench.pmc_traffic(bench.TILE_NAMES[16])["traffic"] - (8 * 245.9e6 + 19 * 68.9e6) / 27) < 1.0
     assert abs(bench.pmc_traffic(bench.TILE_NAMES[13])["traffic"] - 45.3e6) < 1.0   # ring4, not the two-stage tile
     assert abs(bench.pmc_traffic(bench.TILE_NAMES[9])["traffic"] - 33.0e6) < 1.0
+    assert bench.pmc_traffic(bench.TILE_NAMES[18])["traffic_kernel_tree_sha"] == kernel_tree_sha()
+    # a profile of OTHER kernels (an older round's, or none recorded): null, with the reason — never a stale number
+    json.dump({"kernels": ks, "kernel_tree_sha": "0123456789abcdef"}, open(prof / "r99_pmc.json", "w"))
+    stale = bench.pmc_traffic(bench.TILE_NAMES[18])
+    assert stale["traffic"] is None and "0123456789abcdef" in stale["traffic_note"]
+    json.dump({"kernels": ks}, open(prof / "r99_pmc.json", "w"))
+    assert bench.pmc_traffic(bench.TILE_NAMES[18])["traffic"] is None
 
 
 def test_bench_rates_gemms_against_their_true_bound():

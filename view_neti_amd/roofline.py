@@ -10,6 +10,9 @@ import torch
 
 from . import ops
 
+import os as _os
+
+_CSRC = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "csrc")
 MFMA_PEAK_TFLOPS = 2500.0  # fp16/bf16 dense MFMA peak
 HBM_PEAK_TBS = 8.0         # HBM3E spec peak
 PF, TB = MFMA_PEAK_TFLOPS, HBM_PEAK_TBS
@@ -20,7 +23,7 @@ def kernel_tree_sha() -> str:
     (tools/pmc_summary.py) and bench.py quotes a committed `traffic` figure only when the stamp matches the tree it runs"""
     import hashlib
     import os
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    here = _CSRC
     files = sorted(os.path.join(here, f) for f in os.listdir(here) if f.endswith((".hip", ".h")))
     files.append(os.path.join(os.path.dirname(os.path.dirname(here)), "include", "vneti.h"))
     h = hashlib.sha256()
