@@ -265,9 +265,15 @@ class Coach:
             raise NotImplementedError("original_ti: the reference's own path raises AttributeError "
                                       "(net_clip_text_embedding.py:80 on the tensor neti_mapper.py:183-192 returns)")
         if cfg.learnable_mode == 1 and Path(str(cfg.data.fixed_object_token_or_path)).exists():
-            # coach.py:554-558: a pretrained object mapper kept frozen beside the trained view mapper
+            # Upstream this combination is unfinished: coach.py:554-557 loads the pretrained object mapper into a LOCAL that is
+            # never used again, `mapper_object_lookup` stays None in mode 1 (:493,508; "todo: option to keep learning a
+            # pretrained object mapper", :669), so NeTICLIPTextEmbeddings embeds the placeholder token through its plain
+            # (super-category-initialised) table row (net_clip_text_embedding.py:65) — the checkpoint is silently ignored.
+            # Reproducing that would train a view mapper against an object the user did not ask for: refuse instead.
             raise NotImplementedError("learnable_mode 1 with a pretrained object mapper (fixed_object_token_or_path is a "
-                                      "file): the engine has no frozen object bucket; a vocabulary word works")
+                                      ".pt file): the reference itself loads that mapper and never uses it "
+                                      "(training/coach.py:554-557, mapper_object_lookup stays None); pass a vocabulary "
+                                      "word, or train object and view mapper together with learnable_mode 2")
         if (m.bypass_unconstrained_object and not m.output_bypass_object) or \
                 (m.bypass_unconstrained_view and not m.output_bypass_view):
             raise ValueError("bypass_unconstrained needs output_bypass (neti_mapper.py:130-132)")
