@@ -409,9 +409,25 @@ def main():
         # N GPUs = the one-GPU graph + ONE collective node; a rank that silently fell back to [graph A -> host all-reduce ->
         # graph B] would cost the scaling target and nobody would see why: make that an error (engine/step.py capture())
         os.environ.setdefault("VNETI_REQUIRE_ONE_GRAPH", "1")
-    cfg, eng = build_engine(args, rank, world)
-    if not args.no_graph:
-        eng.capture()
+    one_graph_error = None
+    try:
+        cfg, eng = build_engine(args, rank, world)
+        if not args.no_graph:
+            eng.capture()
+    except RuntimeError as err:
+        # the one-graph route was REQUIRED and is not available on this node (the requirement fails on every rank together:
+        # parallel.all_agree).  A measurement with the reason attached beats no measurement: take the two-graph route and
+        # say so in the line (`exchange_in_graph` false, `one_graph_error`).
+        if not (world > 1 and os.environ.get("VNETI_REQUIRE_ONE_GRAPH") == "1"):
+            raise
+        one_graph_error = f"{type(err).__name__}: {str(err)[:300]}"
+        print(f"[bench rank {rank}] one-graph route unavailable, falling back: {one_graph_error}", file=sys.stderr, flush=True)
+        os.environ["VNETI_REQUIRE_ONE_GRAPH"] = "0"
+        eng = None
+        torch.cuda.empty_cache()
+        cfg, eng = build_engine(args, rank, world)
+        if not args.no_graph:
+            eng.capture()
     for _ in range(args.warmup):
         eng.step()
 
@@ -476,6 +492,7 @@ def main():
                        "exchange": (None if world == 1 else "vneti_allreduce_flat (library RCCL communicator, captured node)"
                                     if eng.exchange_in_graph else "library RCCL communicator between two graphs"
                                     if eng.exchange is not None else f"torch.distributed.all_reduce ({backend}) between two graphs"),
+                       "one_graph_error": one_graph_error,
                        "picks_identical_on_all_ranks": picks_equal,
                        "final_loss": loss,
                        "algorithmic_tflop_per_step": ALGO_GFLOP_PER_SAMPLE_512 * args.batch * (args.resolution / 512) ** 2 / 1e3,
