@@ -173,6 +173,8 @@ class TrainStepEngine:
             self._batch_cached = False    # does the batch set by set_batch() consist of cached images only
             self._batch_images = ()
         self.graph_a_c = self.graph_acc_c = None  # the captured step without the VAE encoder (moments from the cache)
+        from .staging import HostStager
+        self.stager = HostStager()
         self.need_backward = need_backward
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
@@ -192,18 +194,25 @@ class TrainStepEngine:
             raise ValueError("the object mapper may not change inside a gradient-accumulation group")
         self.active_object = object_index
         self.obj_slot.fill_(object_index)
-        if pixel_values is not None:  # None: the device input pipeline already wrote self.pixel_values
-            self.pixel_values.copy_(pixel_values, non_blocking=True)
-        if self.n_cache:
-            if image_idx is None:
-                raise ValueError("the moment cache needs the dataset index of every image of the batch (image_idx)")
-            ids = tuple(int(i) for i in image_idx)
-            if min(ids) < 0 or max(ids) >= self.n_cache:
-                raise ValueError(f"image_idx {ids} outside the moment cache (0..{self.n_cache - 1})")
-            self.img_idx.copy_(torch.as_tensor(ids, dtype=torch.int64), non_blocking=True)
-            self._batch_images = ids
-            self._batch_cached = all(i in self._cached_images for i in ids)
-        self.text.set_batch(input_ids, placeholder_object, placeholder_view, view_params)
+        # every host -> device upload of the batch goes through a pinned staging slot (engine/staging.py): the host does not
+        # wait for the previous step's graph, it enqueues the copies behind it and moves on
+        st = self.stager
+        st.begin()
+        try:
+            if self.n_cache:
+                if image_idx is None:
+                    raise ValueError("the moment cache needs the dataset index of every image of the batch (image_idx)")
+                ids = tuple(int(i) for i in image_idx)
+                if min(ids) < 0 or max(ids) >= self.n_cache:
+                    raise ValueError(f"image_idx {ids} outside the moment cache (0..{self.n_cache - 1})")
+                st.upload("img_idx", self.img_idx, torch.as_tensor(ids, dtype=torch.int64))
+                self._batch_images = ids
+                self._batch_cached = all(i in self._cached_images for i in ids)
+            self.text.set_batch(input_ids, placeholder_object, placeholder_view, view_params, upload=st.upload)
+            if pixel_values is not None:  # None: the device input pipeline already wrote self.pixel_values
+                st.upload("pixels", self.pixel_values, pixel_values)  # (large: a blocking copy, issued LAST)
+        finally:
+            st.end()
 
     def train(self, mode: bool = True):
         """nested dropout is a training-time feature (neti_mapper.py:403); eval() turns the draws off.
@@ -224,7 +233,10 @@ class TrainStepEngine:
         self.timesteps.copy_(timesteps)
 
     def set_lr(self, lr: float):
-        self.hyper[0] = lr
+        st = self.stager  # (a scalar write `hyper[0] = lr` is a blocking upload too)
+        st.begin()
+        st.upload("lr", self.hyper[0:1], torch.tensor([lr], dtype=torch.float32))
+        st.end()
 
     # ------------------------------------------------------------------ the step
     def forward_backward(self, accumulate: bool = False, cached: bool = False):

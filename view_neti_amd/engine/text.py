@@ -168,9 +168,13 @@ class TextEngine(Schedule):
 
     # ------------------------------------------------------------------ batch plumbing
     def set_batch(self, input_ids: torch.Tensor, placeholder_object: torch.Tensor,
-                  placeholder_view: Optional[torch.Tensor] = None, view_params: Optional[torch.Tensor] = None):
+                  placeholder_view: Optional[torch.Tensor] = None, view_params: Optional[torch.Tensor] = None, upload=None):
         """Host-side equivalent of the `locs = (input_ids == placeholder)` bookkeeping of
-        models/net_clip_text_embedding.py:95-97,127-129 (one placeholder per row, asserted)."""
+        models/net_clip_text_embedding.py:95-97,127-129 (one placeholder per row, asserted).
+        upload(name, device_tensor, host_tensor): how the per-batch index buffers reach the device (the train step passes its
+        pinned stager, engine/staging.py; default: a plain blocking copy_)."""
+        if upload is None:
+            upload = lambda name, dev, host: dev.copy_(host)
         B, L, nl = self.B, self.L, self.nl
         ids = input_ids.cpu()
         assert tuple(ids.shape) == (B, L)
@@ -188,21 +192,21 @@ class TextEngine(Schedule):
             po = torch.full((B,), -1, dtype=torch.int32)
         else:
             po = positions(placeholder_object)
-        self.ids.copy_(ids)
-        self.pos_obj.copy_(po)
+        upload("ids", self.ids, ids)
+        upload("pos_obj", self.pos_obj, po)
         base = (torch.arange(nl).view(nl, 1) * B + torch.arange(B).view(1, B)) * L
         # rows of the residual stream whose dX the mapper backward gathers; -1 (no placeholder in the prompt) = no gradient:
         # the mapper's output reached nothing, its bucket segment must stay frozen (vneti_mapper_bwd zeroes such rows)
-        self.rows_obj.copy_(torch.where(po.view(1, B) >= 0, base + po.view(1, B), torch.full_like(base, -1))
-                            .reshape(-1).to(torch.int32))
+        upload("rows_obj", self.rows_obj, torch.where(po.view(1, B) >= 0, base + po.view(1, B), torch.full_like(base, -1))
+               .reshape(-1).to(torch.int32))
         if self.mv is not None:
-            if placeholder_view is None or bool((placeholder_view == -1).all()):
+            if placeholder_view is None or bool((placeholder_view.cpu() == -1).all()):
                 self.pos_view.fill_(-1)
             else:
                 pv = positions(placeholder_view)
-                self.pos_view.copy_(pv)
-                self.rows_view.copy_((base + pv.view(1, B)).reshape(-1).to(torch.int32))
-                self.view_params.copy_(view_params.float())
+                upload("pos_view", self.pos_view, pv)
+                upload("rows_view", self.rows_view, (base + pv.view(1, B)).reshape(-1).to(torch.int32))
+                upload("view_params", self.view_params, view_params.float())
 
     # ------------------------------------------------------------------ schedule
     def _mapper_bufs(self, m: MapperState, nfeat):
