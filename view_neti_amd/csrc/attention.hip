@@ -703,8 +703,7 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnA
     // f32 partials: ws[qs][0 = dK (unscaled) | 1 = dV][b*Nk + key][h*D + d]
     if (kok) {
       const long long plane = (long long)a.Bn * a.Nk * a.H * D;
-      float* kp = a.ws + ((long long)qs * 2) * plane + ((long long)b * a.Nk + key) * (a.H * D) + h * D;
-      float* vp = kp + plane;
+      const __amdgpu_buffer_rsrc_t rsP = vn_make_rsrc(a.ws, 0xfffffff0u);
 #pragma unroll
       for (int db = 0; db < C::DB; ++db)
 #pragma unroll
@@ -713,8 +712,10 @@ __global__ __launch_bounds__(256, (D >= 160 ? 1 : 2)) void attn_dkv_kernel(AttnA
           if (d < D) {
             f32x4 k4 = {dk[db][4 * qd], dk[db][4 * qd + 1], dk[db][4 * qd + 2], dk[db][4 * qd + 3]};
             f32x4 v4 = {dv[db][4 * qd], dv[db][4 * qd + 1], dv[db][4 * qd + 2], dv[db][4 * qd + 3]};
-            *reinterpret_cast<f32x4*>(kp + d) = k4;
-            *reinterpret_cast<f32x4*>(vp + d) = v4;
+            // (write-through: 126 MB of f32 partials at 64 x 64 must not sit dirty in L2 at the kernel boundary)
+            const uint32_t po = (uint32_t)(((((long long)qs * 2) * plane + ((long long)b * a.Nk + key) * (a.H * D) + h * D + d)) * 4);
+            vn_st16_wt(rsP, po, k4);
+            vn_st16_wt(rsP, po + (uint32_t)(plane * 4), v4);
           }
         }
     }
@@ -1148,7 +1149,8 @@ extern "C" int vneti_attn_bwd_dkv(const void* Q, long long ldq, const void* K, l
     if (qsplit > nqt / 4) qsplit = nqt / 4;
     if (qsplit > 32) qsplit = 32;
     const long long plane = (long long)Bn * Nk * H * D;
-    while (qsplit > 1 && 2LL * qsplit * plane > ws_floats) --qsplit;
+    // (the partials are stored through 32-bit buffer offsets: keep the slab under 4 GiB as well)
+    while (qsplit > 1 && (2LL * qsplit * plane > ws_floats || 8LL * qsplit * plane >= (1LL << 32) - 64)) --qsplit;
     if (qsplit < 2) qsplit = 1;
   }
   a.qsplit = qsplit;

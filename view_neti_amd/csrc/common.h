@@ -76,6 +76,19 @@ __device__ __forceinline__ u32x4 vn_buf_load16(__amdgpu_buffer_rsrc_t r, uint32_
 __device__ __forceinline__ u32x2 vn_buf_load8(__amdgpu_buffer_rsrc_t r, uint32_t off) {
   return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
 }
+// Write-through (sc1) 16-byte store of a kernel's OUTPUT through a buffer resource (base wave-uniform, byte offset < 2 GiB
+// like every tensor here).  A plain store leaves the line dirty in the XCD's L2 until the end-of-kernel release writes it back —
+// on the critical path between two dependent launches (boundary cost + dirty bytes / 6 TB/s, MI355X_MICROARCH.md price list).
+// With sc1 the line goes to the fabric while the kernel is still running; nothing re-reads an output inside the launch that
+// wrote it, and the next launch's acquire invalidates L2 anyway.  Round 6, same box, same picks: 38.5 -> 40.7 steps/s
+// (profiles/r06_wt_stores_ab*.txt).  The builtin keeps the store visible to the compiler's hazard and waitcnt passes (an
+// inline-asm store needed hand-placed wait states and still broke two epilogues).
+constexpr int VN_CPOL_SC1 = 16;  // aux / cache-policy bit 4: sc1 on gfx940+
+template <typename V>
+__device__ __forceinline__ void vn_st16_wt(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, const V v) {
+  static_assert(sizeof(V) == 16, "16-byte stores only: narrower sc1 stores are one fabric write each");
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, byte_off, 0, VN_CPOL_SC1);
+}
 __device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ u32x4 as_u32x4(half8 v) { return __builtin_bit_cast(u32x4, v); }
 __device__ __forceinline__ half4 as_half4(u32x2 v) { return __builtin_bit_cast(half4, v); }

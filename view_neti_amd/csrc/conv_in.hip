@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvInArgs a) {
     const long long m = m_blk + (wave * 4 + g) * 16 + frow;
     const bool mok = m < M;
     const half8 pf = pfs[g];
-    half_t* orow = a.out + m * a.ldo + nb * 128;
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
       half8 o;
@@ -110,7 +109,8 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvInArgs a) {
           }
         }
       }
-      if (mok) *reinterpret_cast<half8*>(orow + c4 * 32 + fq * 8) = o;
+      if (mok)  // write-through (common.h vn_st16_wt): 268 MB of output at 512 x 512 leave L2 while the kernel runs
+        vn_st16_wt(vn_make_rsrc(a.out, 0x7fffffffu), (uint32_t)((m * a.ldo + nb * 128 + c4 * 32 + fq * 8) * 2), o);
     }
   }
 

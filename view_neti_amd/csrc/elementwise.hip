@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void add_kernel(const half_t* a, long long lda
   half8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)x[j] + (float)y[j]);
-  *reinterpret_cast<half8*>(out + (long long)r * ldo + c) = o;
+  vn_st16_wt(vn_make_rsrc(out, 0x7fffffffu), (uint32_t)(((long long)r * ldo + c) * 2), o);
 }
 
 // GEGLU: p = [h | g] (each C4 wide); out = h * gelu_erf(g)
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void sum2x2_kernel(const half_t* in, long long
   half8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
-  *reinterpret_cast<half8*>(out + pix * ldo + c) = o;
+  vn_st16_wt(vn_make_rsrc(out, 0x7fffffffu), (uint32_t)((pix * ldo + c) * 2), o);
 }
 
 // ---- device RNG -----------------------------------------------------------------------------

@@ -680,6 +680,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   // ---- split-K: raw f32 partials straight to the workspace ----
   if (g.ksplit > 1) {
     float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
+    const __amdgpu_buffer_rsrc_t rsW = vn_make_rsrc(ws, 0x7fffffffu);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
             if (m < g.M && n < g.N) {
               float* p = ws + (long long)m * g.N + n;
               if (n + 4 <= g.N && (g.N & 3) == 0) {
-                *reinterpret_cast<f32x4*>(p) = acc[h][j][i][jb];
+                vn_st16_wt(rsW, (uint32_t)(((long long)m * g.N + n) * 4), acc[h][j][i][jb]);
               } else {
                 for (int e = 0; e < 4 && n + e < g.N; ++e) p[e] = acc[h][j][i][jb][e];
               }
@@ -736,6 +737,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
   // every fused operand (residual, row-add, gate: buffer loads, out-of-range => zeros) of a batch are requested before
   // any of them is used, so a tile pays 16 / U memory round trips instead of 16 serialised ones. ----
   half_t* Cb = reinterpret_cast<half_t*>(g.C) + (long long)bz * g.strideC;
+  const __amdgpu_buffer_rsrc_t rsC = vn_make_rsrc(Cb, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t rsC2 = vn_make_rsrc(e_C2, e_C2 ? 0x7fffffffu : 0u);
   const half_t* Rb = reinterpret_cast<const half_t*>(g.resid);
   if (Rb) Rb += (long long)bz * g.strideC;
   constexpr int CPR = BN / 8;
@@ -845,7 +848,6 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
         }
         if (e_geglu == 2) {
           // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]
-          half_t* dp = Cb + (long long)m * g.ldc + 2 * n;
 #pragma unroll
           for (int c2 = 0; c2 < 2; ++c2) {
             const half8 pre = c2 == 0 ? gv[u] : gv2[u];
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
               o[e] = (half_t)(d * gg * cdf);
               o[4 + e] = (half_t)(d * hh * (cdf + xpdf));
             }
-            *reinterpret_cast<half8*>(dp + 8 * c2) = o;
+            vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + 2 * n + 8 * c2) * 2), o);
           }
           continue;
         }
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)gv[u][e], g.gate_act));
         }
-        *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
+        vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + n) * 2), v);
         if (e_geglu == 1) {
           half4 o2;
 #pragma unroll
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
           half8 o2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o2[e] = (half_t)apply_act((float)v[e], g.act2);
-          *reinterpret_cast<half8*>(e_C2 + (long long)m * g.ldc2 + n) = o2;
+          vn_st16_wt(rsC2, (uint32_t)(((long long)m * g.ldc2 + n) * 2), o2);
         }
       } else {  // ragged last chunk (N % 8 != 0): element-wise, operands straight from memory
         const half_t* radd = e_rowadd ? e_rowadd + (long long)(m / g.rows_per_group) * g.ld_rowadd + n : nullptr;

@@ -384,6 +384,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
   // ---- split-K: raw f32 partials straight to the workspace ---------------------------------
   if (g.ksplit > 1) {
     float* ws = g.ws + ((long long)(kz * g.batch + bz) * g.M) * g.N;
+    const __amdgpu_buffer_rsrc_t rsW = vn_make_rsrc(ws, 0x7fffffffu);
 #pragma unroll
     for (int i = 0; i < MI16; ++i)
 #pragma unroll
@@ -393,7 +394,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
         if (m < g.M && n < g.N) {
           float* p = ws + (long long)m * g.N + n;
           if (n + 4 <= g.N && (g.N & 3) == 0) {
-            *reinterpret_cast<f32x4*>(p) = acc[i][j];
+            vn_st16_wt(rsW, (uint32_t)(((long long)m * g.N + n) * 4), acc[i][j]);
           } else {
             for (int e = 0; e < 4 && n + e < g.N; ++e) p[e] = acc[i][j][e];
           }
@@ -437,6 +438,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
   // ---- epilogue phase 2: coalesced row-major stores with fused row-add / residual ------
   if constexpr (F32OUT) {
     float* Cb = reinterpret_cast<float*>(g.C) + (long long)bz * g.strideC;
+    const __amdgpu_buffer_rsrc_t rsC = vn_make_rsrc(Cb, 0x7fffffffu);
     const float* Rb = reinterpret_cast<const float*>(g.resid);
     if (Rb) Rb += (long long)bz * g.strideC;
     constexpr int CPR = BN / 4;
@@ -450,7 +452,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
           f32x4 rr = *reinterpret_cast<const f32x4*>(Rb + (long long)m * g.ldr + n);
           v += rr;
         }
-        *reinterpret_cast<f32x4*>(Cb + (long long)m * g.ldc + n) = v;
+        vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + n) * 4), v);
       } else {
         for (int e = 0; e < 4 && n + e < g.N; ++e) {
           float x = v[e];
@@ -461,6 +463,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
     }
   } else {
     half_t* Cb = reinterpret_cast<half_t*>(g.C) + (long long)bz * g.strideC;
+    const __amdgpu_buffer_rsrc_t rsC = vn_make_rsrc(Cb, 0x7fffffffu);
+    const __amdgpu_buffer_rsrc_t rsC2 = vn_make_rsrc(e_C2, e_C2 ? 0x7fffffffu : 0u);
     const half_t* Rb = reinterpret_cast<const half_t*>(g.resid);
     if (Rb) Rb += (long long)bz * g.strideC;
     constexpr int CPR = BN / 8;
@@ -532,7 +536,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
         if (e_geglu == 2) {
           // GEGLU backward: v = d(h * gelu(g)) for 8 outputs; the saved pre-activation holds [h0..3 g0..3 h4..7 g4..7]
           const half_t* pp = e_gate + (long long)m * g.ld_gate + 2 * n;
-          half_t* dp = Cb + (long long)m * g.ldc + 2 * n;
 #pragma unroll
           for (int c2 = 0; c2 < 2; ++c2) {
             const half8 pre = *reinterpret_cast<const half8*>(pp + 8 * c2);
@@ -545,7 +548,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
               o[e] = (half_t)(d * gg * cdf);
               o[4 + e] = (half_t)(d * hh * (cdf + xpdf));
             }
-            *reinterpret_cast<half8*>(dp + 8 * c2) = o;
+            vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + 2 * n + 8 * c2) * 2), o);
           }
           continue;
         }
@@ -554,7 +557,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)pre[e], g.gate_act));
         }
-        *reinterpret_cast<half8*>(Cb + (long long)m * g.ldc + n) = v;
+        vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + n) * 2), v);
         if (e_geglu == 1) {
           half4 o2;
 #pragma unroll
@@ -578,7 +581,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
           half8 o2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o2[e] = (half_t)apply_act((float)v[e], g.act2);
-          *reinterpret_cast<half8*>(e_C2 + (long long)m * g.ldc2 + n) = o2;
+          vn_st16_wt(rsC2, (uint32_t)(((long long)m * g.ldc2 + n) * 2), o2);
         }
       } else {
         for (int e = 0; e < 8 && n + e < g.N; ++e) {
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
     if (g.out_f32) {
       f32x4 o = {x[0], x[1], x[2], x[3]};
       if (g.resid) o += rf;
-      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + co) = o;
+      vn_st16_wt(vn_make_rsrc(g.C, 0x7fffffffu), (uint32_t)(co * 4), o);
     } else {
       half4 o, o2;
 #pragma unroll

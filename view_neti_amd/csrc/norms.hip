@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
                                                        float eps = 0.f, float* __restrict__ mean_out = nullptr,
                                                        float* __restrict__ rstd_out = nullptr) {
   const int slab = blockIdx.x, b = blockIdx.y;
+  const __amdgpu_buffer_rsrc_t rsO = vn_make_rsrc(out, 0x7fffffffu);  // write-through output stores (common.h vn_st16_wt)
   int tx, ty;
   bool active;
   gn_thread_coords(g, tx, ty, active);
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
             if (SILU) z = vn_silu(z);
             ov[j] = (half_t)z;
           }
-          *reinterpret_cast<half8*>(out + ((long long)b * g.HW + r + u * g.TY) * ldo + ch0) = ov;
+          vn_st16_wt(rsO, (uint32_t)((((long long)b * g.HW + r + u * g.TY) * ldo + ch0) * 2), ov);
         }
       }
     }
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
           ov[j] = (half_t)dx;
         }
       }
-      *reinterpret_cast<half8*>(out + row * ldo + ch0) = ov;
+      vn_st16_wt(rsO, (uint32_t)((row * ldo + ch0) * 2), ov);
     }
   }
 }
@@ -606,16 +607,17 @@ __device__ __forceinline__ void ln_load(const void* x, long long off, float v[8]
 }
 template <bool F32>
 __device__ __forceinline__ void ln_store(void* y, long long off, const float v[8]) {
+  // write-through (common.h vn_st16_wt): `y` is the kernel argument, wave-uniform
+  const __amdgpu_buffer_rsrc_t rs = vn_make_rsrc(y, 0x7fffffffu);
   if (F32) {
-    float* p = reinterpret_cast<float*>(y) + off;
     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-    *reinterpret_cast<f32x4*>(p) = a;
-    *reinterpret_cast<f32x4*>(p + 4) = b;
+    vn_st16_wt(rs, (uint32_t)(off * 4), a);
+    vn_st16_wt(rs, (uint32_t)(off * 4 + 16), b);
   } else {
     half8 h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(y) + off) = h;
+    vn_st16_wt(rs, (uint32_t)(off * 2), h);
   }
 }
 
