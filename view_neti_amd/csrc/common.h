@@ -83,11 +83,24 @@ __device__ __forceinline__ u32x2 vn_buf_load8(__amdgpu_buffer_rsrc_t r, uint32_t
 // wrote it, and the next launch's acquire invalidates L2 anyway.  Round 6, same box, same picks: 38.5 -> 40.7 steps/s
 // (profiles/r06_wt_stores_ab*.txt).  The builtin keeps the store visible to the compiler's hazard and waitcnt passes (an
 // inline-asm store needed hand-placed wait states and still broke two epilogues).
+constexpr int VN_CPOL_NT = 2;    // aux bit 1: non-temporal (streaming) hint
 constexpr int VN_CPOL_SC1 = 16;  // aux / cache-policy bit 4: sc1 on gfx940+
 template <typename V>
 __device__ __forceinline__ void vn_st16_wt(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, const V v) {
   static_assert(sizeof(V) == 16, "16-byte stores only: narrower sc1 stores are one fabric write each");
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, byte_off, 0, VN_CPOL_SC1);
+}
+// Tensors that are written in the forward pass and read ONLY by the backward pass, milliseconds later (the GEGLU
+// pre-activation p: 0.6 GB per step; a pre-activation stored beside its activated copy, e.g. CLIP fc1), and their single read
+// there, carry the non-temporal hint on top: they would only push soon-needed lines out of the caches.  Round 6, same box, same
+// picks: +0.3 ... 0.4 % on the step (profiles/r06_nt_saved_ab1/2.txt).
+__device__ __forceinline__ u32x4 vn_buf_load16_once(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, VN_CPOL_NT);
+}
+template <typename V>
+__device__ __forceinline__ void vn_st16_wt_saved(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, const V v) {
+  static_assert(sizeof(V) == 16, "16-byte stores only");
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, byte_off, 0, VN_CPOL_SC1 | VN_CPOL_NT);
 }
 __device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ u32x4 as_u32x4(half8 v) { return __builtin_bit_cast(u32x4, v); }

@@ -816,8 +816,8 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
       }
       if (EPI == 2 && e_gate) {
         const long long go = (long long)m * g.ld_gate + (e_geglu == 2 ? 2 * n : n);
-        gv[u] = as_half8(vn_buf_load16(rsG, ok ? (uint32_t)(go * 2) : VN_OOB));
-        gv2[u] = as_half8(vn_buf_load16(rsG, (ok && e_geglu == 2) ? (uint32_t)(go * 2 + 16) : VN_OOB));
+        gv[u] = as_half8(vn_buf_load16_once(rsG, ok ? (uint32_t)(go * 2) : VN_OOB));
+        gv2[u] = as_half8(vn_buf_load16_once(rsG, (ok && e_geglu == 2) ? (uint32_t)(go * 2 + 16) : VN_OOB));
       }
     }
 #pragma unroll
@@ -868,7 +868,9 @@ __global__ __launch_bounds__(NT) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)gv[u][e], g.gate_act));
         }
-        vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + n) * 2), v);
+        // (the GEGLU pre-activation p, and a pre-activation stored beside its activated copy C2, are read by the backward only)
+        if (e_geglu == 1 || (e_C2 && e_geglu == 0)) vn_st16_wt_saved(rsC, (uint32_t)(((long long)m * g.ldc + n) * 2), v);
+        else vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + n) * 2), v);
         if (e_geglu == 1) {
           half4 o2;
 #pragma unroll

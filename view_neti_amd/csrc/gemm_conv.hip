@@ -557,7 +557,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * act_grad((float)pre[e], g.gate_act));
         }
-        vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + n) * 2), v);
+        // (the GEGLU pre-activation p, and a pre-activation stored beside its activated copy C2, are read by the backward only)
+        if (e_geglu == 1 || (e_C2 && e_geglu == 0)) vn_st16_wt_saved(rsC, (uint32_t)(((long long)m * g.ldc + n) * 2), v);
+        else vn_st16_wt(rsC, (uint32_t)(((long long)m * g.ldc + n) * 2), v);
         if (e_geglu == 1) {
           half4 o2;
 #pragma unroll
