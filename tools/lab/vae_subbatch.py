@@ -34,7 +34,11 @@ e4 = VAEEncoderEngine(cfg.vae, w, 4, 512, 512)
 e4.x_in.normal_()
 t4 = timed(e4, 10, 1)
 del e4
+e2 = VAEEncoderEngine(cfg.vae, w, 2, 512, 512)
+e2.x_in.normal_()
+t2 = timed(e2, 10, 2)
+del e2
 e1 = VAEEncoderEngine(cfg.vae, w, 1, 512, 512)
 e1.x_in.normal_()
 t1 = timed(e1, 10, 4)
-print(f"VAE encoder bs 4 in one pass: {t4:.3f} ms; four bs-1 passes: {t1:.3f} ms")
+print(f"VAE encoder bs 4 in one pass: {t4:.3f} ms; two bs-2 passes: {t2:.3f} ms; four bs-1 passes: {t1:.3f} ms")
