@@ -352,7 +352,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNGeom g, const half_t* _
         half8 xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          xv[u] = *reinterpret_cast<const half8*>(x + ((long long)b * g.HW + r + u * g.TY) * ldx + ch0);
+          // non-temporal: after this read x is needed again only by the backward, milliseconds later (never, for the VAE) —
+          // it must not push the y lines the next convolution is about to read out of the caches (+0.25 % on the step,
+          // profiles/r06_gn_nt_load_ab1.txt; the same hint on the backward kernels' operands measured +-0, _ab2)
+          xv[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(x + ((long long)b * g.HW + r + u * g.TY) * ldx + ch0));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           half8 ov;
